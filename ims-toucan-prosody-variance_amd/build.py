@@ -1,0 +1,53 @@
+"""Builds libtoucan_hip.so (gfx950) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libtoucan_hip.so")
+SOURCES = ["conv1d.hip", "rowops.hip", "attention.hip", "sequence_ops.hip", "capi.hip"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "toucan_tts.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into one shared object next to the package."""
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    bdir = os.path.join(PKG, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,99 @@
+"""ctypes binding of include/toucan_tts.h (libtoucan_hip.so).
+
+The library is mandatory: there is no CPU or PyTorch fallback anywhere in the product path.
+``lib()`` raises if the shared object is missing or does not export the full ABI.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtoucan_hip.so")
+
+MODE_LINEAR, MODE_GLU, MODE_GATED, MODE_COUPLING = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+PRE_NONE, PRE_LRELU = 0, 1
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
+
+_p = C.c_void_p
+_i = C.c_int32
+_f = C.c_float
+
+
+class TtsTile(C.Structure):
+    _fields_ = [("row0", _i), ("seq_begin", _i), ("seq_end", _i), ("seq_id", _i)]
+
+
+class TtsConvDesc(C.Structure):
+    _fields_ = [
+        ("x", _p), ("ldx", _i), ("cin", _i),
+        ("w", _p), ("cin_pad", _i), ("wn", _i), ("half_pad", _i),
+        ("bias", _p),
+        ("y", _p), ("ldy", _i), ("cout", _i),
+        ("taps", _i), ("dil", _i), ("pad_left", _i),
+        ("pre_act", _i), ("pre_slope", _f),
+        ("mode", _i), ("act", _i), ("alpha", _f),
+        ("seqvec", _p), ("ld_seqvec", _i),
+        ("preadd", _p), ("ld_preadd", _i),
+        ("res", _p), ("ld_res", _i), ("res_scale", _f),
+        ("aux", _p), ("ld_aux", _i),
+        ("accumulate", _i),
+        ("compute", _i),
+        ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
+    ]
+
+
+# symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
+PROTOTYPES = {
+    "tts_last_error": (C.c_char_p, []),
+    "tts_abi_version": (C.c_int, []),
+    "tts_conv1d_tile_rows": (C.c_int, [_i, _i]),
+    "tts_conv1d_n_tile": (C.c_int, [_i, _i]),
+    "tts_conv1d": (C.c_int, [C.POINTER(TtsConvDesc), _p]),
+    "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
+    "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
+    "tts_l2_normalize": (C.c_int, [_p, _p, _i, _i, _p]),
+    "tts_groupnorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _i, _p]),
+    "tts_relpos_attention": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
+    "tts_dwconv_swish": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _p]),
+    "tts_duration_from_log": (C.c_int, [_p, _p, _i, _p]),
+    "tts_prosody_control": (C.c_int, [_p, _i, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _p]),
+    "tts_length_regulate": (C.c_int, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _f, _p]),
+    "tts_glow_invconv_actnorm": (C.c_int, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "tts_snake_aa": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _p]),
+    "tts_conv_post": (C.c_int, [_p, _i, _i, _p, _f, _i, _f, _p, _p, _i, _i, _p]),
+    "tts_gather_rows": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _p]),
+    "tts_axpby": (C.c_int, [_p, _i, _f, _p, _i, _f, _p, _i, _i, _i, _p]),
+}
+
+_LIB = None
+
+
+class ToucanHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libtoucan_hip.so and bind every symbol of the ABI; raise loudly if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ToucanHipError(
+            f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
+            f"Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise ToucanHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = handle
+    return handle
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().tts_last_error().decode("utf-8", "replace")
+        raise ToucanHipError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,558 @@
+"""Host-side sequencing of the HIP kernels: acoustic model and vocoders.
+
+Python only orders launches and owns the buffers (torch tensors = device memory); every arithmetic
+operation of the forward pass is a call into libtoucan_hip.so (capi.py).  There is no torch compute
+on the path and no CPU fallback.
+
+Layout: activations are time-major [rows, channels], all utterances of the batch packed along rows
+(ragged.py).  The reference mirrors are cited per method.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import capi, packing
+from .capi import (ACT_NONE, ACT_RELU, ACT_TANH, COMPUTE_BF16, COMPUTE_F32, MODE_COUPLING, MODE_GATED, MODE_GLU, MODE_LINEAR,
+                   PRE_LRELU, PRE_NONE)
+from .ragged import Ragged
+
+ATT, HEADS, DK = 192, 4, 48
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _ld(t):
+    if t is None:
+        return 0
+    if t.dim() == 1:
+        return 1
+    assert t.stride(-1) == 1, "kernels need unit channel stride"
+    return t.stride(0)
+
+
+class Ops:
+    """Thin typed wrappers over the C ABI; all launches go to the current torch stream of `device`."""
+
+    def __init__(self, device):
+        self.lib = capi.lib()
+        self.device = torch.device(device)
+
+    def stream(self):
+        if self.device.type == "cuda":
+            return torch.cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def conv(self, cw, x, y, rag, pre=PRE_NONE, pre_slope=0.0, act=ACT_NONE, alpha=1.0, seqvec=None, preadd=None, res=None,
+             res_scale=1.0, aux=None, accumulate=False, compute=COMPUTE_F32):
+        tiles, n_tiles = rag.tiles(cw.tile_rows)
+        d = capi.TtsConvDesc()
+        d.x, d.ldx, d.cin = x.data_ptr(), _ld(x), cw.cin
+        use_bf16 = compute == COMPUTE_BF16 and cw.w_bf16 is not None
+        d.w = cw.w_bf16.data_ptr() if use_bf16 else cw.w.data_ptr()
+        d.cin_pad, d.wn, d.half_pad = cw.cin_pad, cw.wn, cw.half_pad
+        d.bias = _ptr(cw.bias)
+        d.y, d.ldy, d.cout = y.data_ptr(), _ld(y), cw.cout
+        d.taps, d.dil, d.pad_left = cw.taps, cw.dil, cw.pad_left
+        d.pre_act, d.pre_slope = pre, pre_slope
+        d.mode, d.act, d.alpha = cw.mode, act, alpha
+        d.seqvec, d.ld_seqvec = _ptr(seqvec), _ld(seqvec)
+        d.preadd, d.ld_preadd = _ptr(preadd), _ld(preadd)
+        d.res, d.ld_res, d.res_scale = _ptr(res), _ld(res), res_scale
+        d.aux, d.ld_aux = _ptr(aux), _ld(aux)
+        d.accumulate = 1 if accumulate else 0
+        d.compute = COMPUTE_BF16 if use_bf16 else COMPUTE_F32
+        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, cw.tile_rows
+        capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
+        return y
+
+    def layernorm(self, x, y, gamma, beta, rows, c, eps=1e-12):
+        capi.check(self.lib.tts_layernorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), gamma.data_ptr(), beta.data_ptr(), rows, c, eps,
+                                          self.stream()), "tts_layernorm")
+        return y
+
+    def cond_layernorm(self, x, y, scale, shift, c, rag):
+        tiles, n = rag.tiles(64)
+        capi.check(self.lib.tts_cond_layernorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), scale.data_ptr(), shift.data_ptr(), c,
+                                               tiles.data_ptr(), n, 64, self.stream()), "tts_cond_layernorm")
+        return y
+
+    def l2_normalize(self, x, y):
+        capi.check(self.lib.tts_l2_normalize(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], self.stream()), "tts_l2_normalize")
+        return y
+
+    def groupnorm(self, x, y, gamma, beta, c, groups, rag, tanh, res=None, eps=1e-5):
+        sb, se = rag.bounds()
+        capi.check(self.lib.tts_groupnorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), gamma.data_ptr(), beta.data_ptr(), c, groups, eps,
+                                          1 if tanh else 0, _ptr(res), _ld(res), sb.data_ptr(), se.data_ptr(), rag.n_seq, self.stream()),
+                   "tts_groupnorm")
+        return y
+
+    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag):
+        tiles, n = rag.tiles(64)
+        capi.check(self.lib.tts_relpos_attention(qkv.data_ptr(), _ld(qkv), ptab.data_ptr(), pmax, bias_u.data_ptr(), bias_v.data_ptr(),
+                                                 ctx.data_ptr(), _ld(ctx), HEADS, DK, tiles.data_ptr(), n, 64, self.stream()),
+                   "tts_relpos_attention")
+        return ctx
+
+    def dwconv_swish(self, x, y, w, b, c, k, rag):
+        tiles, n = rag.tiles(64)
+        capi.check(self.lib.tts_dwconv_swish(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), w.data_ptr(), b.data_ptr(), c, k,
+                                             tiles.data_ptr(), n, 64, self.stream()), "tts_dwconv_swish")
+        return y
+
+    def duration_from_log(self, logd, dur):
+        capi.check(self.lib.tts_duration_from_log(logd.data_ptr(), dur.data_ptr(), logd.numel(), self.stream()), "tts_duration_from_log")
+
+    def prosody_control(self, text, pitch, energy, dur, rag, duration_scale, pitch_scale, energy_scale, pause_scale):
+        sb, se = rag.bounds()
+        capi.check(self.lib.tts_prosody_control(text.data_ptr(), _ld(text), pitch.data_ptr(), energy.data_ptr(), dur.data_ptr(),
+                                                sb.data_ptr(), se.data_ptr(), rag.n_seq, duration_scale, pitch_scale, energy_scale,
+                                                pause_scale, self.stream()), "tts_prosody_control")
+
+    def length_regulate(self, enc, pitch, energy, wp, bp, we, be, dur, rag_phone, rag_frame, up, dec_in, dec_scale):
+        pb, pe = rag_phone.bounds()
+        fb, _ = rag_frame.bounds()
+        capi.check(self.lib.tts_length_regulate(enc.data_ptr(), _ld(enc), pitch.data_ptr(), energy.data_ptr(), wp.data_ptr(),
+                                                bp.data_ptr(), we.data_ptr(), be.data_ptr(), dur.data_ptr(), pb.data_ptr(), pe.data_ptr(),
+                                                fb.data_ptr(), rag_phone.n_seq, rag_frame.max_len, rag_phone.max_len, enc.shape[1],
+                                                up.data_ptr(), _ld(up), _ptr(dec_in), _ld(dec_in), dec_scale, self.stream()),
+                   "tts_length_regulate")
+
+    def glow_invconv_actnorm(self, x, rows, c, winv, an_bias, an_logs):
+        capi.check(self.lib.tts_glow_invconv_actnorm(x.data_ptr(), _ld(x), rows, c, winv.data_ptr(), an_bias.data_ptr(), an_logs.data_ptr(),
+                                                     self.stream()), "tts_glow_invconv_actnorm")
+
+    def snake_aa(self, x, y, alpha, beta, filt, c, rag):
+        tiles, n = rag.tiles(64)
+        capi.check(self.lib.tts_snake_aa(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), alpha.data_ptr(), beta.data_ptr(), filt.data_ptr(), c,
+                                         tiles.data_ptr(), n, 64, self.stream()), "tts_snake_aa")
+        return y
+
+    def conv_post(self, x, cin, w, bias, pre, slope, wav, rag):
+        tiles, n = rag.tiles(256)
+        capi.check(self.lib.tts_conv_post(x.data_ptr(), _ld(x), cin, w.data_ptr(), bias, pre, slope, wav.data_ptr(), tiles.data_ptr(), n,
+                                          256, self.stream()), "tts_conv_post")
+        return wav
+
+    def gather_rows(self, src, idx, dst):
+        capi.check(self.lib.tts_gather_rows(src.data_ptr(), _ld(src), idx.data_ptr(), dst.data_ptr(), _ld(dst), idx.numel(), src.shape[1],
+                                            self.stream()), "tts_gather_rows")
+        return dst
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+class ConformerWeights:
+    """Packed weights of one Layers/Conformer.py stack (6 EncoderLayers)."""
+
+    def __init__(self, sd, prefix, kernel, device):
+        self.kernel = kernel
+        self.blocks = []
+        for b in range(6):
+            p = f"{prefix}.encoders.{b}."
+            blk = {}
+            for ln in ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final"):
+                blk[ln] = (_dev(sd[p + ln + ".weight"], device), _dev(sd[p + ln + ".bias"], device))
+            for ff in ("feed_forward_macaron", "feed_forward"):
+                blk[ff + ".w1"] = packing.pack_conv(sd[p + ff + ".w_1.weight"], sd[p + ff + ".w_1.bias"], device)
+                blk[ff + ".w2"] = packing.pack_conv(sd[p + ff + ".w_2.weight"], sd[p + ff + ".w_2.bias"], device)
+            a = p + "self_attn."
+            wqkv = np.concatenate([sd[a + f"linear_{n}.weight"] for n in "qkv"], axis=0)
+            bqkv = np.concatenate([sd[a + f"linear_{n}.bias"] for n in "qkv"], axis=0)
+            blk["qkv"] = packing.pack_conv(wqkv, bqkv, device)
+            blk["out"] = packing.pack_conv(sd[a + "linear_out.weight"], sd[a + "linear_out.bias"], device)
+            blk["pos"] = packing.pack_conv(sd[a + "linear_pos.weight"], None, device)
+            blk["u"] = _dev(sd[a + "pos_bias_u"].reshape(-1), device)
+            blk["v"] = _dev(sd[a + "pos_bias_v"].reshape(-1), device)
+            c = p + "conv_module."
+            blk["pw1"] = packing.pack_conv(sd[c + "pointwise_conv1.weight"], sd[c + "pointwise_conv1.bias"], device, mode=MODE_GLU)
+            # BatchNorm1d eval (running stats, eps 1e-5) folded into the depthwise conv: Convolution.py:26-27,50-51
+            g = sd[c + "norm.weight"].astype(np.float64) / np.sqrt(sd[c + "norm.running_var"].astype(np.float64) + 1e-5)
+            dw = sd[c + "depthwise_conv.weight"][:, 0, :].astype(np.float64) * g[:, None]  # [c, k]
+            db = (sd[c + "depthwise_conv.bias"].astype(np.float64) - sd[c + "norm.running_mean"].astype(np.float64)) * g \
+                + sd[c + "norm.bias"].astype(np.float64)
+            blk["dw_w"] = _dev(dw.T, device)  # [k][c]
+            blk["dw_b"] = _dev(db, device)
+            blk["pw2"] = packing.pack_conv(sd[c + "pointwise_conv2.weight"], sd[c + "pointwise_conv2.bias"], device)
+            self.blocks.append(blk)
+        self.pmax = 0
+        self.ptabs = None
+
+
+class AcousticEngine:
+    """InferenceToucanTTS.ToucanTTS (:16-319) for a ragged batch of utterances."""
+
+    def __init__(self, state_dict, device):
+        self.ops = Ops(device)
+        self.device = self.ops.device
+        dev = self.device
+        sd = packing.fold_weight_norm(state_dict)
+        self.multilingual = "encoder.language_embedding.weight" in sd
+        self.multispeaker = "encoder.hs_emb_projection.weight" in sd
+        if not self.multispeaker:
+            raise NotImplementedError("single-speaker checkpoints (LayerNorm predictors) are not supported by the HIP path yet")
+        pc = packing.pack_conv
+        self.embed0 = pc(sd["encoder.embed.0.weight"], sd["encoder.embed.0.bias"], dev)
+        self.embed2 = pc(sd["encoder.embed.2.weight"], sd["encoder.embed.2.bias"], dev)
+        self.lang_table = _dev(sd["encoder.language_embedding.weight"], dev) if self.multilingual else None
+        self.enc = ConformerWeights(sd, "encoder", 7, dev)
+        self.dec = ConformerWeights(sd, "decoder", 31, dev)
+        self.out_norm = (_dev(sd["encoder.output_norm.weight"], dev), _dev(sd["encoder.output_norm.bias"], dev))
+        hs = sd["encoder.hs_emb_projection.weight"]
+        self.hs_h = pc(hs[:, :ATT], None, dev)  # acts on the hidden states
+        self.hs_e = pc(hs[:, ATT:], sd["encoder.hs_emb_projection.bias"], dev)  # acts on the utterance embedding (+ bias)
+        self.pred = {}
+        for name, layers, k in (("pitch_predictor", 7, 5), ("energy_predictor", 2, 3), ("duration_predictor", 3, 3)):
+            convs = [pc(sd[f"{name}.conv.{i}.0.weight"], sd[f"{name}.conv.{i}.0.bias"], dev) for i in range(layers)]
+            mlps = []
+            for i in range(layers):
+                m = {}
+                for which in ("W_scale", "W_bias"):
+                    q = f"{name}.norms.{i}.{which}."
+                    m[which] = [pc(sd[q + f"{j}.weight"], sd[q + f"{j}.bias"], dev) for j in (0, 2, 4)]
+                mlps.append(m)
+            lin = pc(sd[name + ".linear.weight"], sd[name + ".linear.bias"], dev)
+            self.pred[name] = (convs, mlps, lin)
+        self.pitch_w = _dev(sd["pitch_embed.0.weight"].reshape(-1), dev)
+        self.pitch_b = _dev(sd["pitch_embed.0.bias"], dev)
+        self.energy_w = _dev(sd["energy_embed.0.weight"].reshape(-1), dev)
+        self.energy_b = _dev(sd["energy_embed.0.bias"], dev)
+        self.feat_out = pc(sd["feat_out.weight"], sd["feat_out.bias"], dev)
+        self.postnet = [(pc(sd[f"conv_postnet.postnet.{i}.0.weight"], None, dev), _dev(sd[f"conv_postnet.postnet.{i}.1.weight"], dev),
+                         _dev(sd[f"conv_postnet.postnet.{i}.1.bias"], dev)) for i in range(5)]
+        # PostFlow
+        self.g_proj = pc(sd["post_flow.g_proj.weight"], sd["post_flow.g_proj.bias"], dev)
+        self.flow = []
+        for b in range(18):
+            pa, pn, pcp = (f"post_flow.flows.{3 * b + i}." for i in range(3))
+            blk = dict(an_bias=_dev(sd[pa + "bias"].reshape(-1), dev), an_logs=_dev(sd[pa + "logs"].reshape(-1), dev),
+                       winv=_dev(packing.invconv_inverse(sd, pn), dev),
+                       start=pc(sd[pcp + "start.weight"], sd[pcp + "start.bias"], dev),
+                       end=pc(sd[pcp + "end.weight"], sd[pcp + "end.bias"], dev, mode=MODE_COUPLING),
+                       cond=pc(sd[pcp + "wn.cond_layer.weight"], sd[pcp + "wn.cond_layer.bias"], dev))
+            if b % 4 == 0 or not self.flow:  # in/res-skip layers are shared inside groups of 4 blocks (Glow.py:325-327)
+                shared = dict(inl=[], res=[], skip=[])
+                for i in range(4):
+                    shared["inl"].append(pc(sd[pcp + f"wn.in_layers.{i}.weight"], sd[pcp + f"wn.in_layers.{i}.bias"], dev, mode=MODE_GATED))
+                    rw, rb = sd[pcp + f"wn.res_skip_layers.{i}.weight"], sd[pcp + f"wn.res_skip_layers.{i}.bias"]
+                    if i < 3:  # first half feeds the residual stream, second half the skip sum (wavenet.py:112-118)
+                        shared["res"].append(pc(rw[:ATT], rb[:ATT], dev))
+                        shared["skip"].append(pc(rw[ATT:], rb[ATT:], dev))
+                    else:
+                        shared["res"].append(None)
+                        shared["skip"].append(pc(rw, rb, dev))
+            blk.update(shared)
+            self.flow.append(blk)
+        self._pe_cache = {}
+
+    # ---- relative position tables -----------------------------------------------------------------
+    def _ensure_ptabs(self, cw, pmax):
+        """ptab_l[pmax-1+p] = linear_pos_l(pe(p)) for every block l (Attention.py:177, PositionalEncoding.py:90-130)."""
+        if cw.pmax >= pmax:
+            return
+        pmax = max(pmax, 2 * cw.pmax, 256)
+        ops = self.ops
+        pe = _dev(packing.rel_pos_encoding(pmax), self.device)
+        rag = Ragged([2 * pmax - 1], self.device)
+        cw.ptabs = [ops.conv(blk["pos"], pe, ops.empty(2 * pmax - 1, ATT), rag) for blk in cw.blocks]
+        cw.pmax = pmax
+
+    # ---- Conformer stack ---------------------------------------------------------------------------
+    def _conformer(self, cw, x, rag, taps=None, tap_name=None):
+        """Layers/EncoderLayer.py:62-144 x6; x is the residual stream [rows,192], already scaled by sqrt(192)."""
+        ops = self.ops
+        R = x.shape[0]
+        self._ensure_ptabs(cw, rag.max_len)
+        ln = ops.empty(R, ATT)
+        hid = ops.empty(R, 1536)
+        qkv = ops.empty(R, 3 * ATT)
+        ctx = ops.empty(R, ATT)
+        glu = ops.empty(R, ATT)
+        dwo = ops.empty(R, ATT)
+        for li, blk in enumerate(cw.blocks):
+            for ff, norm in (("feed_forward_macaron", "norm_ff_macaron"),):
+                ops.layernorm(x, ln, *blk[norm], R, ATT)
+                ops.conv(blk[ff + ".w1"], ln, hid, rag, act=ACT_RELU)
+                ops.conv(blk[ff + ".w2"], hid, x, rag, alpha=0.5, res=x)
+            ops.layernorm(x, ln, *blk["norm_mha"], R, ATT)
+            ops.conv(blk["qkv"], ln, qkv, rag)
+            ops.attention(qkv, cw.ptabs[li], cw.pmax, blk["u"], blk["v"], ctx, rag)
+            ops.conv(blk["out"], ctx, x, rag, res=x)
+            ops.layernorm(x, ln, *blk["norm_conv"], R, ATT)
+            ops.conv(blk["pw1"], ln, glu, rag)
+            ops.dwconv_swish(glu, dwo, blk["dw_w"], blk["dw_b"], ATT, cw.kernel, rag)
+            ops.conv(blk["pw2"], dwo, x, rag, res=x)
+            ops.layernorm(x, ln, *blk["norm_ff"], R, ATT)
+            ops.conv(blk["feed_forward.w1"], ln, hid, rag, act=ACT_RELU)
+            ops.conv(blk["feed_forward.w2"], hid, x, rag, alpha=0.5, res=x)
+            ops.layernorm(x, x, *blk["norm_final"], R, ATT)
+            if taps is not None:
+                taps[f"{tap_name}_block{li}"] = x.clone()
+        return x
+
+    def _predictor(self, name, enc, e_norm, rag, rag_b):
+        """Layers/VariancePredictor.py:65-80 / DurationPredictor.py:63-74 with ConditionalLayerNorm.py:52-67."""
+        ops = self.ops
+        convs, mlps, lin = self.pred[name]
+        R, B = enc.shape[0], e_norm.shape[0]
+        h = enc
+        a, bbuf = ops.empty(R, 256), ops.empty(R, 256)
+        t64, t256 = ops.empty(B, 64), ops.empty(B, 256)
+        for i, cw in enumerate(convs):
+            sc_sh = []
+            for which in ("W_scale", "W_bias"):
+                m = mlps[i][which]
+                ops.conv(m[0], e_norm, t64, rag_b, act=ACT_TANH)
+                ops.conv(m[1], t64, t256, rag_b, act=ACT_TANH)
+                sc_sh.append(ops.conv(m[2], t256, ops.empty(B, 256), rag_b))
+            ops.conv(cw, h, a, rag, act=ACT_RELU)
+            ops.cond_layernorm(a, bbuf, sc_sh[0], sc_sh[1], 256, rag)
+            h = bbuf  # the next conv reads bbuf into a, then the norm overwrites bbuf: no aliasing
+        out = ops.empty(R, 1)
+        ops.conv(lin, h, out, rag)
+        return out.view(-1)
+
+    @torch.inference_mode()
+    def forward(self, texts, utt_embs, lang_ids=None, durations=None, pitch=None, energy=None, z_noise=None,
+                duration_scaling_factor=1.0, pitch_variance_scale=1.0, energy_variance_scale=1.0,
+                pause_duration_scaling_factor=1.0, run_postflow=True, taps=None, generator=None):
+        """texts: list of [L_u,62] float tensors; utt_embs: [B,64]; lang_ids: list of int or None;
+        durations/pitch/energy: optional lists (gold values, InferenceToucanTTS.py:209-211);
+        z_noise: optional list of [80, T_u] tensors = 0.8*N(0,1) (Glow.py:363) - drawn on the device if omitted.
+        Returns dict(mel=[list of [T'_u,80]], durations, pitch, energy, plus packed tensors)."""
+        ops, dev = self.ops, self.device
+        B = len(texts)
+        assert duration_scaling_factor > 0
+        Ls = [int(t.shape[0]) for t in texts]
+        rag_p = Ragged(Ls, dev)
+        rag_b = Ragged([B], dev)
+        R = rag_p.total_rows
+        text = torch.cat([t.reshape(-1, 62).to(torch.float32) for t in texts], dim=0).to(dev).contiguous()
+        emb = utt_embs.to(dev, torch.float32).reshape(B, 64).contiguous()
+        e_norm = ops.l2_normalize(emb, ops.empty(B, 64))
+
+        # ---- encoder: Conformer.py:92-134 ----
+        h100 = ops.conv(self.embed0, text, ops.empty(R, 100), rag_p, act=ACT_TANH)
+        seqvec = None
+        if self.multilingual and lang_ids is not None:
+            idx = torch.tensor([int(i) for i in lang_ids], dtype=torch.int32).to(dev)
+            seqvec = ops.gather_rows(self.lang_table, idx, ops.empty(B, ATT))
+        x = ops.conv(self.embed2, h100, ops.empty(R, ATT), rag_p, seqvec=seqvec, alpha=math.sqrt(ATT))
+        if taps is not None:
+            taps["enc_embed_scaled"] = x.clone()
+        x = self._conformer(self.enc, x, rag_p, taps, "enc")
+        ops.layernorm(x, x, *self.out_norm, R, ATT)
+        e_proj = ops.conv(self.hs_e, e_norm, ops.empty(B, ATT), rag_b)
+        enc = ops.conv(self.hs_h, x, ops.empty(R, ATT), rag_p, seqvec=e_proj)
+
+        # ---- variance predictors ----
+        def packed_gold(lst, dtype):
+            return torch.cat([torch.as_tensor(v).reshape(-1).to(dtype) for v in lst]).to(dev).contiguous()
+
+        p = self._predictor("pitch_predictor", enc, e_norm, rag_p, rag_b) if pitch is None else packed_gold(pitch, torch.float32)
+        en = self._predictor("energy_predictor", enc, e_norm, rag_p, rag_b) if energy is None else packed_gold(energy, torch.float32)
+        if durations is None:
+            logd = self._predictor("duration_predictor", enc, e_norm, rag_p, rag_b)
+            d = ops.empty(R, dtype=torch.int32)
+            ops.duration_from_log(logd, d)
+            if taps is not None:
+                taps["log_dur"] = logd.clone()
+        else:
+            d = packed_gold(durations, torch.int32)
+        if taps is not None:
+            taps.update(enc_out=enc.clone(), pitch_raw=p.clone(), energy_raw=en.clone())
+        ops.prosody_control(text, p, en, d, rag_p, duration_scaling_factor, pitch_variance_scale, energy_variance_scale,
+                            pause_duration_scaling_factor)
+
+        # ---- the one host round trip: frame counts fix every later buffer size ----
+        d_host = d.cpu().numpy()
+        Ts = []
+        for b0, n in zip(rag_p.begins, rag_p.lengths):
+            t = int(d_host[b0:b0 + n].sum())
+            Ts.append(t if t > 0 else n)  # LengthRegulator.py:52-53 (all-zero utterance -> all ones)
+        rag_f = Ragged(Ts, dev, align=2)  # even begins so that the Glow squeeze is a pure re-view
+        RF = rag_f.total_rows
+
+        # ---- length regulator + pitch/energy embedding (InferenceToucanTTS.py:230-235) ----
+        cat = torch.zeros(RF, 80 + ATT, dtype=torch.float32, device=dev)  # [refined mel | upsampled text] = g_proj input
+        up = cat[:, 80:]
+        dec_x = ops.empty(RF, ATT)
+        ops.length_regulate(enc, p, en, self.pitch_w, self.pitch_b, self.energy_w, self.energy_b, d, rag_p, rag_f, up, dec_x,
+                            math.sqrt(ATT))
+        if taps is not None:
+            taps["upsampled"] = up.clone()
+
+        # ---- decoder + feat_out (InferenceToucanTTS.py:238-239) ----
+        dec_x = self._conformer(self.dec, dec_x, rag_f, taps, "dec")
+        mel0 = ops.conv(self.feat_out, dec_x, ops.empty(RF, 80), rag_f)
+
+        # ---- PostNet (PostNet.py:62-74) + residual (InferenceToucanTTS.py:241) ----
+        a, bb = ops.empty(RF, 256), ops.empty(RF, 256)
+        src = mel0
+        for i, (cw, gw, gb) in enumerate(self.postnet):
+            if i < 4:
+                ops.conv(cw, src, a, rag_f)  # reads src (mel0 or bb) -> a
+                ops.groupnorm(a, bb, gw, gb, 256, 32, rag_f, tanh=True)  # a -> bb
+                src = bb
+            else:
+                y80 = ops.conv(cw, src, ops.empty(RF, 80), rag_f)
+                ops.groupnorm(y80, cat[:, :80], gw, gb, 80, 20, rag_f, tanh=False, res=mel0)
+        refined = cat[:, :80]
+        out = dict(durations_packed=d, pitch_packed=p, energy_packed=en, rag_phone=rag_p, rag_frame=rag_f, decoded_packed=mel0,
+                   refined_packed=refined)
+
+        if run_postflow:
+            mel_packed, rag_out = self._postflow(cat, rag_f, z_noise, taps, generator)
+        else:
+            mel_packed, rag_out = refined, rag_f
+        out["mel_packed"], out["rag_mel"] = mel_packed, rag_out
+        out["mel"] = [mel_packed[b0:b0 + n] for b0, n in zip(rag_out.begins, rag_out.lengths)]
+        out["durations"] = [d[b0:b0 + n] for b0, n in zip(rag_p.begins, rag_p.lengths)]
+        out["pitch"] = [p[b0:b0 + n] for b0, n in zip(rag_p.begins, rag_p.lengths)]
+        out["energy"] = [en[b0:b0 + n] for b0, n in zip(rag_p.begins, rag_p.lengths)]
+        return out
+
+    def _postflow(self, cat, rag_f, z_noise, taps, generator):
+        """Glow.forward(infer=True) + _forward(reverse=True): Glow.py:342-391."""
+        ops, dev = self.ops, self.device
+        RF = cat.shape[0]
+        g = ops.conv(self.g_proj, cat, ops.empty(RF, ATT), rag_f)
+        if taps is not None:
+            taps["glow_g"] = g.clone()
+        rag_s = rag_f.halved()
+        RS = RF // 2
+        g_sq = g.view(RS, 2 * ATT)  # squeeze == re-view in time-major layout (glow_utils.py:28-40)
+        x = torch.zeros(RS, 160, dtype=torch.float32, device=dev)
+        if z_noise is None:
+            # Glow.py:363: z ~ 0.8 * N(0,1), drawn per squeezed row on the device
+            z = torch.randn(RS, 160, device=dev, dtype=torch.float32, generator=generator) * 0.8
+            x.copy_(z)
+        else:
+            for zu, b0, n in zip(z_noise, rag_s.begins, rag_s.lengths):
+                zt = torch.as_tensor(zu, dtype=torch.float32).t()[: 2 * n].reshape(n, 160)
+                x[b0:b0 + n].copy_(zt)
+        h = ops.empty(RS, ATT)
+        acts = ops.empty(RS, ATT)
+        skip = ops.empty(RS, ATT)
+        cond = ops.empty(RS, 8 * ATT)
+        for b in reversed(range(18)):
+            blk = self.flow[b]
+            ops.conv(blk["start"], x[:, :80], h, rag_s)
+            ops.conv(blk["cond"], g_sq, cond, rag_s)
+            for i in range(4):
+                ops.conv(blk["inl"][i], h, acts, rag_s, preadd=cond[:, i * 2 * ATT:(i + 1) * 2 * ATT])
+                if i < 3:
+                    ops.conv(blk["res"][i], acts, h, rag_s, res=h)
+                ops.conv(blk["skip"][i], acts, skip, rag_s, accumulate=(i > 0))
+            x1 = x[:, 80:]
+            ops.conv(blk["end"], skip, x1, rag_s, aux=x1)
+            ops.glow_invconv_actnorm(x, RS, 160, blk["winv"], blk["an_bias"], blk["an_logs"])
+            if taps is not None and b in (17, 8, 0):
+                taps[f"glow_z_after_block{b}"] = x.clone()
+        mel = x.view(2 * RS, 80)  # unsqueeze == re-view (glow_utils.py:43-53)
+        rag_out = Ragged([2 * n for n in rag_s.lengths], dev, begins=[2 * b for b in rag_s.begins])
+        return mel, rag_out
+
+
+class VocoderEngine:
+    """BigVGAN (InferenceBigVGAN.py:72-95) / Avocodo-HiFiGAN generator (InferenceAvocodo.py:69-80) on packed mels."""
+
+    UP = ((8, 16), (6, 12), (4, 8), (2, 4))
+    KS = (3, 7, 11)
+    DIL = (1, 3, 5)
+
+    def __init__(self, state_dict, kind, device, bf16=False):
+        assert kind in ("bigvgan", "hifigan")
+        self.kind = kind
+        self.ops = Ops(device)
+        self.device = self.ops.device
+        self.compute = COMPUTE_BF16 if bf16 else COMPUTE_F32
+        dev = self.device
+        sd = packing.fold_weight_norm(state_dict)
+        if kind == "bigvgan":
+            pre, ups, blk, c1, c2, post = "conv_pre", "ups.{}.0", "resblocks.{}.", "convs1.{}", "convs2.{}", "conv_post"
+        else:
+            pre, ups, blk, c1, c2, post = "input_conv", "upsamples.{}.1", "blocks.{}.", "convs1.{}.1", "convs2.{}.1", "output_conv.1"
+        pc = packing.pack_conv
+        self.pre = pc(sd[pre + ".weight"], sd[pre + ".bias"], dev, bf16=bf16)
+        self.ups, self.blocks, self.snakes = [], [], []
+        for i, (u, k) in enumerate(self.UP):
+            self.ups.append(packing.pack_conv_transpose(sd[ups.format(i) + ".weight"], sd[ups.format(i) + ".bias"], u, dev, bf16=bf16))
+            stage, stage_sn = [], []
+            for j, kk in enumerate(self.KS):
+                b = blk.format(3 * i + j)
+                convs, sn = [], []
+                for dd, dil in enumerate(self.DIL):
+                    convs.append((pc(sd[b + c1.format(dd) + ".weight"], sd[b + c1.format(dd) + ".bias"], dev, dil=dil, bf16=bf16),
+                                  pc(sd[b + c2.format(dd) + ".weight"], sd[b + c2.format(dd) + ".bias"], dev, dil=1, bf16=bf16)))
+                    if kind == "bigvgan":
+                        sn.append(tuple((_dev(sd[b + f"activations.{2 * dd + q}.act.alpha"], dev),
+                                         _dev(sd[b + f"activations.{2 * dd + q}.act.beta"], dev)) for q in (0, 1)))
+                stage.append(convs)
+                stage_sn.append(sn)
+            self.blocks.append(stage)
+            self.snakes.append(stage_sn)
+        pw = sd[post + ".weight"]  # [1, 32, 7]
+        self.post_w = _dev(np.ascontiguousarray(pw[0].T), dev)  # [7][32]
+        self.post_b = float(sd[post + ".bias"][0])
+        if kind == "bigvgan":
+            self.post_snake = (_dev(sd["activation_post.act.alpha"], dev), _dev(sd["activation_post.act.beta"], dev))
+            self.filt = _dev(packing.kaiser_sinc_filter12(), dev)
+
+    @torch.inference_mode()
+    def forward(self, mel_packed, rag, taps=None):
+        """mel_packed [rows,80] time-major (utterance u at rag.begins[u], rag.lengths[u] frames) -> (wav packed, Ragged)."""
+        ops, cp = self.ops, self.compute
+        big = self.kind == "bigvgan"
+        R = mel_packed.shape[0]
+        x = ops.conv(self.pre, mel_packed, ops.empty(R, 512), rag, compute=cp)
+        ch = 512
+        for i, (u, k) in enumerate(self.UP):
+            ch //= 2
+            # transposed conv as a 3-tap polyphase conv; [R, u*ch] re-viewed as [R*u, ch]
+            y = ops.conv(self.ups[i], x, ops.empty(R, u * ch), rag, pre=PRE_NONE if big else PRE_LRELU, pre_slope=0.1, compute=cp)
+            R, rag = R * u, rag.scaled(u)
+            xs = y.view(R, ch)
+            stage_out = ops.empty(R, ch)
+            t1, t2, sa = ops.empty(R, ch), ops.empty(R, ch), (ops.empty(R, ch) if big else None)
+            for j in range(3):
+                cur = xs
+                bufs = [ops.empty(R, ch), ops.empty(R, ch)]
+                for dd in range(3):
+                    c1, c2 = self.blocks[i][j][dd]
+                    last = dd == 2
+                    if big:  # AMP.py:51-60: a1 -> c1 -> a2 -> c2 -> + x
+                        (a1, b1), (a2, b2) = self.snakes[i][j][dd]
+                        ops.snake_aa(cur, sa, a1, b1, self.filt, ch, rag)
+                        ops.conv(c1, sa, t1, rag, compute=cp)
+                        ops.snake_aa(t1, t2, a2, b2, self.filt, ch, rag)
+                        src2, pre2 = t2, PRE_NONE
+                    else:  # ResidualBlock.py:83-98 with LeakyReLU(0.1)
+                        ops.conv(c1, cur, t1, rag, pre=PRE_LRELU, pre_slope=0.1, compute=cp)
+                        src2, pre2 = t1, PRE_LRELU
+                    if not last:
+                        nxt = bufs[dd % 2]
+                        ops.conv(c2, src2, nxt, rag, pre=pre2, pre_slope=0.1, res=cur, compute=cp)
+                        cur = nxt
+                    else:  # stage output = mean of the three blocks (InferenceBigVGAN.py:82-88)
+                        ops.conv(c2, src2, stage_out, rag, pre=pre2, pre_slope=0.1, alpha=1.0 / 3.0, res=cur, res_scale=1.0 / 3.0,
+                                 accumulate=(j > 0), compute=cp)
+            x = stage_out
+            if taps is not None:
+                taps[f"voc_stage{i}"] = x.clone()
+        wav = ops.empty(R)
+        if big:
+            t = ops.snake_aa(x, ops.empty(R, ch), *self.post_snake, self.filt, ch, rag)
+            ops.conv_post(t, ch, self.post_w, self.post_b, PRE_NONE, 0.0, wav, rag)
+        else:
+            ops.conv_post(x, ch, self.post_w, self.post_b, PRE_LRELU, 0.01, wav, rag)  # InferenceAvocodo.py:53
+        return wav, rag

@@ -1,0 +1,171 @@
+/*
+ * toucan_tts.h - C ABI of the MI355X-native ToucanTTS inference kernels (libtoucan_hip.so).
+ *
+ * The reference (IMS-Toucan) is pure Python/PyTorch and has no FFI of its own
+ * (SURVEY.md 2.2); its "operator interface" for this path is the set of torch module forwards
+ * listed in SURVEY.md section 8(a).  Each entry point below replaces one of those forwards (or a
+ * fixed sub-sequence of one) and cites it.  The only caller is the build's own Python host
+ * (ims-toucan-prosody-variance_amd/engine.py, via ctypes - see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *  - All tensors are fp32 device pointers owned by the caller (torch allocations); nothing here
+ *    allocates, frees or synchronises.  Every call enqueues on the hipStream_t passed last.
+ *  - Activations are TIME-MAJOR and PACKED: a tensor is rows x channels with a row stride `ld`
+ *    (in floats); the utterances of a batch are concatenated along the row axis.  Raggedness is
+ *    described by a tile table (TtsTile[]) that the host builds once per batch and stage: each
+ *    tile names the utterance it belongs to, so halo reads never cross an utterance boundary and
+ *    reads outside [seq_begin, seq_end) return zero (== the reference's per-utterance zero padding).
+ *  - Return value: 0 on success, negative TTS_E_* otherwise; tts_last_error() gives the text.
+ *    No C++ exception crosses the boundary.
+ */
+#ifndef TOUCAN_TTS_H
+#define TOUCAN_TTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tts_stream_t; /* hipStream_t */
+
+#define TTS_OK 0
+#define TTS_E_ARG (-1)     /* inconsistent shapes / unsupported configuration */
+#define TTS_E_LAUNCH (-2)  /* hipLaunch error */
+
+/* One tile of TILE_ROWS consecutive rows of one utterance. */
+typedef struct {
+  int32_t row0;      /* first packed row of the tile */
+  int32_t seq_begin; /* first packed row of the utterance */
+  int32_t seq_end;   /* one past the last packed row of the utterance */
+  int32_t seq_id;    /* utterance index in the batch (rows of per-utterance vectors) */
+} TtsTile;
+
+/* epilogue modes of tts_conv1d */
+#define TTS_MODE_LINEAR 0   /* v = act(acc + bias + seqvec + preadd)                              */
+#define TTS_MODE_GLU 1      /* v = a * sigmoid(g)            (Layers/Convolution.py:47)            */
+#define TTS_MODE_GATED 2    /* v = tanh(a) * sigmoid(g)      (wavenet.py:29-35)                    */
+#define TTS_MODE_COUPLING 3 /* v = (aux - a) * exp(-g)       (Glow.py:260-264, reverse)            */
+#define TTS_ACT_NONE 0
+#define TTS_ACT_RELU 1
+#define TTS_ACT_TANH 2
+#define TTS_PRE_NONE 0
+#define TTS_PRE_LRELU 1
+
+/*
+ * Dense 1-D convolution over the packed time axis as an implicit GEMM on the matrix cores:
+ *   acc[r, n] = sum_j sum_ci pre(x[r + j*dil - pad_left, ci]) * w[j][ci][n]
+ *   y[r, n]   = alpha * epilogue(acc) + res_scale * res[r, n] (+ y[r, n] if accumulate)
+ * Replaces every torch.nn.Conv1d / Linear / ConvTranspose1d on the path:
+ *   Layers/MultiLayeredConv1d.py:50-51 (FFN), Layers/Attention.py:57-59,91,177 (q,k,v,out,pos),
+ *   Layers/Convolution.py:25,28 (pointwise), Layers/VariancePredictor.py:70, DurationPredictor.py:67,
+ *   Layers/PostNet.py:40-56 (convs), Glow.py:232-241,346-348, wavenet.py:64-82 (flow convs),
+ *   InferenceBigVGAN.py:37-46 / InferenceAvocodo.py:29-43 (pre conv, transposed convs as 3-tap
+ *   polyphase convs), AMP.py:22-43 / ResidualBlock.py:60-81 (dilated residual convs).
+ * Weights are packed by the host as [taps][cin_pad][wn] (cin_pad multiple of 32, wn multiple of
+ * the N tile; zero filled); in the dual modes wn holds the two halves [a | g], each `half_pad` wide.
+ */
+typedef struct {
+  const float* x;      int32_t ldx;  int32_t cin;
+  const void*  w;      int32_t cin_pad; int32_t wn; int32_t half_pad;
+  const float* bias;   /* [cout] (dual modes: [2*cout], a then g) or NULL */
+  float* y;            int32_t ldy;  int32_t cout;
+  int32_t taps, dil, pad_left;
+  int32_t pre_act;     float pre_slope;
+  int32_t mode, act;   float alpha;
+  const float* seqvec; int32_t ld_seqvec; /* per-utterance addend [n_seq, cout] or NULL */
+  const float* preadd; int32_t ld_preadd; /* per-row addend (dual: g half at +cout) or NULL */
+  const float* res;    int32_t ld_res; float res_scale;
+  const float* aux;    int32_t ld_aux;    /* COUPLING: x1 */
+  int32_t accumulate;
+  int32_t compute;     /* 0: fp32 MFMA (exact fp32 fma chain); 1: bf16 MFMA, fp32 accumulate */
+  const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows; /* tile_rows must match the kernel's BM */
+} TtsConvDesc;
+
+/* BM (rows per tile) the conv kernel will use for this shape; build the tile table with it. */
+int tts_conv1d_tile_rows(int32_t cout, int32_t mode);
+/* N tile (columns) for this shape: pack weights with wn = roundup(cols, n_tile). */
+int tts_conv1d_n_tile(int32_t cout, int32_t mode);
+int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream);
+
+/* y[r,:] = LayerNorm(x[r,:]) * g + b over `c` channels, eps as given. Layers/LayerNorm.py:24-36 (eps 1e-12). */
+int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta,
+                  int32_t rows, int32_t c, float eps, tts_stream_t stream);
+
+/* Conditional layer norm with the reference's quirk: y = s[u]*(x-mean)/var + b[u] (divide by the
+ * VARIANCE, no eps, no sqrt).  Layers/ConditionalLayerNorm.py:52-67.  scale/shift are [n_seq, c]. */
+int tts_cond_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* scale, const float* shift,
+                       int32_t c, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
+
+/* Row-wise L2 normalisation (torch.nn.functional.normalize, eps 1e-12). InferenceToucanTTS.py:202, Conformer.py:132. */
+int tts_l2_normalize(const float* x, float* y, int32_t rows, int32_t c, tts_stream_t stream);
+
+/* GroupNorm over (c/groups channels x all frames of one utterance) + optional tanh; one launch for the
+ * whole batch. Layers/PostNet.py:44-56. seq_begin/seq_end are device arrays [n_seq]. */
+int tts_groupnorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta,
+                  int32_t c, int32_t groups, float eps, int32_t apply_tanh, const float* res, int32_t ld_res,
+                  const int32_t* seq_begin, const int32_t* seq_end, int32_t n_seq, tts_stream_t stream);
+
+/* Relative-position multi-head self-attention, flash style (scores never reach HBM):
+ *   s[i,j] = ((q_i+u_h).k_j + (q_i+v_h).P[i-j]) / sqrt(dk); softmax over the utterance's keys; ctx = s.v
+ * qkv: [rows, 3*h*dk] (q|k|v), ptab: [2*pmax-1, h*dk] with row (pmax-1+p) = linear_pos(pe(p)).
+ * Layers/Attention.py:159-198 (rel_shift :138-157 folded into the index i-j), :66-92. */
+int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u,
+                         const float* bias_v, float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk,
+                         const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
+
+/* Depthwise conv over time (k taps, zero padded per utterance) + folded BatchNorm(eval) + Swish on the
+ * GLU output. Layers/Convolution.py:50-51, Swish.py:18.  w: [k][c] (BN folded), b: [c]. */
+int tts_dwconv_swish(const float* x, int32_t ldx, float* y, int32_t ldy, const float* w, const float* b, int32_t c,
+                     int32_t k, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
+
+/* Duration head: d = clamp(round(exp(x) - 1), 0) (round half to even). Layers/DurationPredictor.py:79. */
+int tts_duration_from_log(const float* logd, int32_t* dur, int32_t n, tts_stream_t stream);
+
+/* Linguistic overrides + prosody scaling for one batch, one workgroup per utterance.
+ * InferenceToucanTTS.py:214-227 and _scale_variance :333-343. text is [rows, 62]. */
+int tts_prosody_control(const float* text, int32_t ld_text, float* pitch, float* energy, int32_t* dur,
+                        const int32_t* seq_begin, const int32_t* seq_end, int32_t n_seq, float duration_scale,
+                        float pitch_scale, float energy_scale, float pause_scale, tts_stream_t stream);
+
+/* LengthRegulator: frame f of utterance u copies phoneme row src(f) (exclusive scan of durations), fused with
+ * the pitch/energy embedding add (InferenceToucanTTS.py:230-235, Layers/LengthRegulator.py:37-61).
+ * Writes up[f,:] (ld_up) and, if dec_in != NULL, dec_in[f,:] = up * dec_scale (Conformer.py:116 x*sqrt(d)). */
+int tts_length_regulate(const float* enc, int32_t ld_enc, const float* pitch, const float* energy,
+                        const float* wp, const float* bp, const float* we, const float* be, const int32_t* dur,
+                        const int32_t* phone_begin, const int32_t* phone_end, const int32_t* frame_begin,
+                        int32_t n_seq, int32_t max_frames, int32_t max_phones, int32_t c, float* up, int32_t ld_up,
+                        float* dec_in, int32_t ld_dec, float dec_scale, tts_stream_t stream);
+
+/* Glow reverse step after the coupling: InvConvNear^-1 (4x4 on channel groups) then ActNorm^-1, in place.
+ * Glow.py:93-128 (regrouping :102-103,:126-127) and :30-31. x: [rows, c] with c = 160. */
+int tts_glow_invconv_actnorm(float* x, int32_t ldx, int32_t rows, int32_t c, const float* winv /*[4][4]*/,
+                             const float* an_bias, const float* an_logs, tts_stream_t stream);
+
+/* Anti-aliased SnakeBeta: 2x Kaiser-sinc up (12 taps), x + sin^2(x e^a)/(e^b + 1e-9), 2x low-pass down.
+ * BigVGAN/Snake.py:56-69 + alias_free_torch Activation1d (third party, PARITY UNPINNED - see DESIGN.md). */
+int tts_snake_aa(const float* x, int32_t ldx, float* y, int32_t ldy, const float* alpha, const float* beta,
+                 const float* filt /*[12]*/, int32_t c, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
+                 tts_stream_t stream);
+
+/* Final vocoder conv: wav[r] = tanh(b + sum_j sum_ci pre(x[r+j-3, ci]) w[j][ci]); pre = LeakyReLU(slope) or none.
+ * InferenceAvocodo.py:52-59, InferenceBigVGAN.py:92-95. */
+int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w /*[7][cin]*/, float bias, int32_t pre_act,
+                  float pre_slope, float* wav, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
+                  tts_stream_t stream);
+
+/* Elementwise helper: y = a*x + b*z (z may be NULL), rows x c with strides. */
+int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz, float b, float* y, int32_t ldy,
+              int32_t rows, int32_t c, tts_stream_t stream);
+
+/* dst[i,:] = src[idx[i],:] (embedding lookup, Conformer.py:112-114 language_embedding). */
+int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst, int32_t n,
+                    int32_t c, tts_stream_t stream);
+
+const char* tts_last_error(void);
+int tts_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOUCAN_TTS_H */

@@ -1,0 +1,338 @@
+"""TEST INFRASTRUCTURE ONLY: a numpy restatement of the C ABI in include/toucan_tts.h, operating on HOST
+pointers.  It lets the `-m "not gpu"` suite drive the real host code (engine.py, packing.py, ragged.py,
+interface, distributed sharding) end to end on CPU tensors and compare with the oracle, so that sequencing
+and weight-layout bugs are caught without a GPU.  It doubles as the executable specification the GPU
+kernel tests compare each HIP kernel against.
+
+It is never imported by the package: tests install it by monkeypatching ``capi._LIB``.  The product path
+loads libtoucan_hip.so and nothing else.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from ims_toucan_prosody_variance_amd import capi
+
+
+def _arr(ptr, n, dtype=np.float32):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    ct = {np.float32: C.c_float, np.int32: C.c_int32, np.uint16: C.c_uint16}[dtype]
+    return np.ctypeslib.as_array((ct * int(n)).from_address(int(ptr)))
+
+
+def _mat(ptr, rows, cols, ld, dtype=np.float32):
+    """Strided [rows, cols] view on host memory."""
+    if rows == 0:
+        return np.zeros((0, cols), dtype=dtype)
+    flat = _arr(ptr, (rows - 1) * ld + cols, dtype)
+    return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(ld * flat.itemsize, flat.itemsize))
+
+
+def _tiles(ptr, n):
+    return _arr(ptr, 4 * n, np.int32).reshape(n, 4)
+
+
+def _seqs_from_tiles(t):
+    """unique (seq_begin, seq_end, seq_id) in order."""
+    seen, out = set(), []
+    for row0, sb, se, sid in t:
+        if (sb, se, sid) not in seen:
+            seen.add((sb, se, sid))
+            out.append((int(sb), int(se), int(sid)))
+    return out
+
+
+def _bf16_round(a):
+    """round-to-nearest-even to bfloat16, returned as float32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+class Emulator:
+    def __init__(self):
+        self._real = None
+        self._err = b""
+        self.calls = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    # host-only helpers come from the real library (they do not touch a GPU)
+    def _reallib(self):
+        if self._real is None:
+            self._real = C.CDLL(capi.LIB_PATH)
+        return self._real
+
+    def tts_last_error(self):
+        return self._err
+
+    def tts_abi_version(self):
+        return 1
+
+    def tts_conv1d_tile_rows(self, cout, mode):
+        return self._reallib().tts_conv1d_tile_rows(cout, mode)
+
+    def tts_conv1d_n_tile(self, cout, mode):
+        return self._reallib().tts_conv1d_n_tile(cout, mode)
+
+    # ------------------------------------------------------------------------------------------
+    def tts_conv1d(self, dref, stream):
+        self._count("conv1d")
+        d = dref._obj
+        t = _tiles(d.tiles, d.n_tiles)
+        dual = d.mode != capi.MODE_LINEAR
+        if d.compute == capi.COMPUTE_BF16:
+            wraw = _arr(d.w, d.taps * d.cin_pad * d.wn, np.uint16).reshape(d.taps, d.cin_pad // 8, d.wn, 8)
+            w = (wraw.astype(np.uint32) << 16).view(np.float32).transpose(0, 1, 3, 2).reshape(d.taps, d.cin_pad, d.wn)
+        else:
+            w = _arr(d.w, d.taps * d.cin_pad * d.wn).reshape(d.taps, d.cin_pad, d.wn)
+        bias = _arr(d.bias, d.cout * (2 if dual else 1)) if d.bias else None
+        for sb, se, sid in _seqs_from_tiles(t):
+            n = se - sb
+            x = _mat(d.x, se, d.cin, d.ldx)[sb:se].astype(np.float32)
+            if d.pre_act == capi.PRE_LRELU:
+                x = np.where(x > 0, x, x * np.float32(d.pre_slope))
+            if d.compute == capi.COMPUTE_BF16:
+                x = _bf16_round(x)
+            halo = (d.taps - 1) * d.dil
+            xp = np.zeros((n + halo, d.cin), dtype=np.float32)
+            xp[d.pad_left:d.pad_left + n] = x
+            acc = np.zeros((n, d.wn), dtype=np.float64)
+            for j in range(d.taps):
+                acc += xp[j * d.dil:j * d.dil + n].astype(np.float64) @ w[j, :d.cin].astype(np.float64)
+            acc = acc.astype(np.float32)
+            a = acc[:, :d.cout]
+            if bias is not None:
+                a = a + bias[:d.cout]
+            if d.seqvec:
+                a = a + _mat(d.seqvec, sid + 1, d.cout, d.ld_seqvec)[sid]
+            if d.preadd:
+                a = a + _mat(d.preadd, se, d.cout, d.ld_preadd)[sb:se]
+            if dual:
+                g = acc[:, d.half_pad:d.half_pad + d.cout]
+                if bias is not None:
+                    g = g + bias[d.cout:]
+                if d.preadd:
+                    g = g + _mat(d.preadd + 4 * d.cout, se, d.cout, d.ld_preadd)[sb:se]
+                sig = 1.0 / (1.0 + np.exp(-g.astype(np.float64)))
+                if d.mode == capi.MODE_GLU:
+                    v = a * sig
+                elif d.mode == capi.MODE_GATED:
+                    v = np.tanh(a.astype(np.float64)) * sig
+                else:
+                    v = (_mat(d.aux, se, d.cout, d.ld_aux)[sb:se] - a) * np.exp(-g.astype(np.float64))
+            else:
+                v = a
+                if d.act == capi.ACT_RELU:
+                    v = np.maximum(v, 0)
+                elif d.act == capi.ACT_TANH:
+                    v = np.tanh(v.astype(np.float64))
+            v = (np.asarray(v, dtype=np.float32) * np.float32(d.alpha)).astype(np.float32)
+            if d.res:
+                v = v + np.float32(d.res_scale) * _mat(d.res, se, d.cout, d.ld_res)[sb:se]
+            y = _mat(d.y, se, d.cout, d.ldy)
+            if d.accumulate:
+                v = v + y[sb:se]
+            y[sb:se] = v
+        return 0
+
+    def tts_layernorm(self, x, ldx, y, ldy, gamma, beta, rows, c, eps, stream):
+        self._count("layernorm")
+        X = _mat(x, rows, c, ldx).astype(np.float64)
+        m = X.mean(1, keepdims=True)
+        v = ((X - m) ** 2).mean(1, keepdims=True)
+        out = (X - m) / np.sqrt(v + eps) * _arr(gamma, c) + _arr(beta, c)
+        _mat(y, rows, c, ldy)[:] = out.astype(np.float32)
+        return 0
+
+    def tts_cond_layernorm(self, x, ldx, y, ldy, scale, shift, c, tiles, n_tiles, tile_rows, stream):
+        self._count("cond_layernorm")
+        for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
+            X = _mat(x, se, c, ldx)[sb:se].astype(np.float64)
+            m = X.mean(1, keepdims=True)
+            v = ((X - m) ** 2).mean(1, keepdims=True)
+            sc = _mat(scale, sid + 1, c, c)[sid]
+            sh = _mat(shift, sid + 1, c, c)[sid]
+            _mat(y, se, c, ldy)[sb:se] = (sc * ((X - m) / v) + sh).astype(np.float32)
+        return 0
+
+    def tts_l2_normalize(self, x, y, rows, c, stream):
+        self._count("l2_normalize")
+        X = _mat(x, rows, c, c).astype(np.float64)
+        n = np.maximum(np.sqrt((X ** 2).sum(1, keepdims=True)), 1e-12)
+        _mat(y, rows, c, c)[:] = (X / n).astype(np.float32)
+        return 0
+
+    def tts_groupnorm(self, x, ldx, y, ldy, gamma, beta, c, groups, eps, apply_tanh, res, ld_res, seq_begin, seq_end, n_seq, stream):
+        self._count("groupnorm")
+        sb, se = _arr(seq_begin, n_seq, np.int32), _arr(seq_end, n_seq, np.int32)
+        g, b = _arr(gamma, c).astype(np.float64), _arr(beta, c).astype(np.float64)
+        for u in range(n_seq):
+            r0, r1 = int(sb[u]), int(se[u])
+            X = _mat(x, r1, c, ldx)[r0:r1].astype(np.float64)
+            Xg = X.reshape(r1 - r0, groups, c // groups)
+            m = Xg.mean(axis=(0, 2), keepdims=True)
+            v = ((Xg - m) ** 2).mean(axis=(0, 2), keepdims=True)
+            out = ((Xg - m) / np.sqrt(v + eps)).reshape(r1 - r0, c) * g + b
+            if apply_tanh:
+                out = np.tanh(out)
+            if res:
+                out = out + _mat(res, r1, c, ld_res)[r0:r1]
+            _mat(y, r1, c, ldy)[r0:r1] = out.astype(np.float32)
+        return 0
+
+    def tts_relpos_attention(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream):
+        self._count("relpos_attention")
+        hd = heads * dk
+        P = _mat(ptab, 2 * pmax - 1, hd, hd).astype(np.float64)
+        u = _arr(bias_u, hd).astype(np.float64)
+        v = _arr(bias_v, hd).astype(np.float64)
+        for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
+            n = se - sb
+            assert n <= pmax
+            Q = _mat(qkv, se, 3 * hd, ld_qkv)[sb:se].astype(np.float64)
+            q, k, val = Q[:, :hd], Q[:, hd:2 * hd], Q[:, 2 * hd:]
+            rel = np.arange(n)[:, None] - np.arange(n)[None, :] + (pmax - 1)  # table row of p = i - j
+            out = np.zeros((n, hd))
+            for h in range(heads):
+                sl = slice(h * dk, (h + 1) * dk)
+                ac = (q[:, sl] + u[sl]) @ k[:, sl].T
+                bd = np.einsum("id,ijd->ij", q[:, sl] + v[sl], P[rel][:, :, sl])
+                s = (ac + bd) / math.sqrt(dk)
+                s = np.exp(s - s.max(1, keepdims=True))
+                out[:, sl] = (s / s.sum(1, keepdims=True)) @ val[:, sl]
+            _mat(ctx, se, hd, ld_ctx)[sb:se] = out.astype(np.float32)
+        return 0
+
+    def tts_dwconv_swish(self, x, ldx, y, ldy, w, b, c, k, tiles, n_tiles, tile_rows, stream):
+        self._count("dwconv_swish")
+        W = _mat(w, k, c, c).astype(np.float64)
+        B = _arr(b, c).astype(np.float64)
+        h = (k - 1) // 2
+        for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
+            n = se - sb
+            xp = np.zeros((n + k - 1, c))
+            xp[h:h + n] = _mat(x, se, c, ldx)[sb:se]
+            a = B + sum(xp[j:j + n] * W[j] for j in range(k))
+            _mat(y, se, c, ldy)[sb:se] = (a / (1.0 + np.exp(-a))).astype(np.float32)
+        return 0
+
+    def tts_duration_from_log(self, logd, dur, n, stream):
+        self._count("duration_from_log")
+        v = np.rint(np.exp(_arr(logd, n)).astype(np.float32) - np.float32(1.0))
+        _arr(dur, n, np.int32)[:] = np.clip(v, 0, 1e6).astype(np.int32)
+        return 0
+
+    def tts_prosody_control(self, text, ld_text, pitch, energy, dur, seq_begin, seq_end, n_seq, ds, ps, es, pause, stream):
+        self._count("prosody_control")
+        sb, se = _arr(seq_begin, n_seq, np.int32), _arr(seq_end, n_seq, np.int32)
+        for u in range(n_seq):
+            r0, r1 = int(sb[u]), int(se[u])
+            f = _mat(text, r1, 62, ld_text)[r0:r1]
+            p, e, d = _arr(pitch, r1)[r0:r1], _arr(energy, r1)[r0:r1], _arr(dur, r1, np.int32)[r0:r1]
+            p[f[:, 61] == 0] = 0
+            e[f[:, 15] == 0] = 0
+            d[f[:, 21] == 1] = 0
+            if pause != 1.0:
+                m = f[:, 16] == 1
+                d[m] = np.rint(d[m].astype(np.float32) * np.float32(pause)).astype(np.int32)
+            if ds != 1.0:
+                d[:] = np.rint(d.astype(np.float32) * np.float32(ds)).astype(np.int32)
+            for seq, sc in ((p, ps), (e, es)):
+                if sc != 1.0:
+                    avg = seq[seq != 0].mean(dtype=np.float32) if (seq != 0).any() else np.float32(np.nan)
+                    v = ((seq - avg) * np.float32(sc)) + avg
+                    seq[:] = np.where(v < 0, 0, v)
+        return 0
+
+    def tts_length_regulate(self, enc, ld_enc, pitch, energy, wp, bp, we, be, dur, phone_begin, phone_end, frame_begin, n_seq,
+                            max_frames, max_phones, c, up, ld_up, dec_in, ld_dec, dec_scale, stream):
+        self._count("length_regulate")
+        pb, pe, fb = (_arr(a, n_seq, np.int32) for a in (phone_begin, phone_end, frame_begin))
+        Wp, Bp, We, Be = (_arr(a, c) for a in (wp, bp, we, be))
+        for u in range(n_seq):
+            p0, p1 = int(pb[u]), int(pe[u])
+            d = _arr(dur, p1, np.int32)[p0:p1].copy()
+            if d.sum() == 0:
+                d[:] = 1
+            src = np.repeat(np.arange(p0, p1), d)
+            E = _mat(enc, p1, c, ld_enc)
+            P, En = _arr(pitch, p1), _arr(energy, p1)
+            v = E[src] + (P[src, None] * Wp + Bp) + (En[src, None] * We + Be)
+            T = len(src)
+            f0 = int(fb[u])
+            _mat(up, f0 + T, c, ld_up)[f0:f0 + T] = v
+            if dec_in:
+                _mat(dec_in, f0 + T, c, ld_dec)[f0:f0 + T] = v * np.float32(dec_scale)
+        return 0
+
+    def tts_glow_invconv_actnorm(self, x, ldx, rows, c, winv, an_bias, an_logs, stream):
+        self._count("glow_invconv_actnorm")
+        X = _mat(x, rows, c, ldx)
+        W = _arr(winv, 16).reshape(4, 4).astype(np.float64)
+        v = X.astype(np.float64).reshape(rows, 2, c // 4, 2).transpose(0, 1, 3, 2).reshape(rows, 4, c // 4)  # [r, n=(a,r), g]
+        z = np.einsum("on,rng->rog", W, v)
+        z = z.reshape(rows, 2, 2, c // 4).transpose(0, 1, 3, 2).reshape(rows, c)
+        X[:] = ((z - _arr(an_bias, c)) * np.exp(-_arr(an_logs, c).astype(np.float64))).astype(np.float32)
+        return 0
+
+    def tts_snake_aa(self, x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, stream):
+        self._count("snake_aa")
+        f = _arr(filt, 12).astype(np.float64)
+        ea = np.exp(_arr(alpha, c).astype(np.float64))
+        ib = 1.0 / (np.exp(_arr(beta, c).astype(np.float64)) + 1e-9)
+        for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
+            T = se - sb
+            X = _mat(x, se, c, ldx)[sb:se].astype(np.float64)
+            xp = np.concatenate([np.repeat(X[:1], 5, 0), X, np.repeat(X[-1:], 5, 0)], 0)  # replicate pad 5/5
+            full = np.zeros((2 * (T + 10) + 10, c))
+            for m in range(T + 10):  # conv_transpose1d stride 2
+                full[2 * m:2 * m + 12] += xp[m][None, :] * f[:, None]
+            u = 2.0 * full[15:15 + 2 * T]
+            s = u + ib * np.sin(u * ea) ** 2
+            sp = np.concatenate([np.repeat(s[:1], 5, 0), s, np.repeat(s[-1:], 6, 0)], 0)
+            out = np.stack([(sp[2 * t:2 * t + 12] * f[:, None]).sum(0) for t in range(T)], 0)
+            _mat(y, se, c, ldy)[sb:se] = out.astype(np.float32)
+        return 0
+
+    def tts_conv_post(self, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, stream):
+        self._count("conv_post")
+        W = _mat(w, 7, cin, cin).astype(np.float64)
+        for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
+            n = se - sb
+            X = _mat(x, se, cin, ldx)[sb:se].astype(np.float64)
+            if pre_act == capi.PRE_LRELU:
+                X = np.where(X > 0, X, X * pre_slope)
+            xp = np.zeros((n + 6, cin))
+            xp[3:3 + n] = X
+            a = bias + sum((xp[j:j + n] * W[j]).sum(1) for j in range(7))
+            _arr(wav, se)[sb:se] = np.tanh(a).astype(np.float32)
+        return 0
+
+    def tts_gather_rows(self, src, ld_src, idx, dst, ld_dst, n, c, stream):
+        self._count("gather_rows")
+        ii = _arr(idx, n, np.int32)
+        S = _mat(src, int(ii.max()) + 1, c, ld_src)
+        _mat(dst, n, c, ld_dst)[:] = S[ii]
+        return 0
+
+    def tts_axpby(self, x, ldx, a, z, ldz, b, y, ldy, rows, c, stream):
+        self._count("axpby")
+        v = np.float32(a) * _mat(x, rows, c, ldx)
+        if z:
+            v = v + np.float32(b) * _mat(z, rows, c, ldz)
+        _mat(y, rows, c, ldy)[:] = v
+        return 0
+
+
+def install(monkeypatch=None):
+    """Replace the loaded library by the emulator (tests only). Returns the emulator."""
+    emu = Emulator()
+    if monkeypatch is not None:
+        monkeypatch.setattr(capi, "_LIB", emu)
+    else:
+        capi._LIB = emu
+    return emu
