@@ -81,7 +81,11 @@ def lib():
         raise ToucanHipError(
             f"{LIB_PATH} not found: the HIP extension is mandatory (no CPU fallback). "
             f"Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # PyTorch-ROCm ships its own libamdhip64; load it FIRST so that libtoucan_hip.so binds to the same HIP
+    # runtime (same soname) - two runtimes in one process cannot share streams or device pointers.
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
+    _assert_single_hip_runtime()
     for name, (res, args) in PROTOTYPES.items():
         try:
             fn = getattr(handle, name)
@@ -91,6 +95,16 @@ def lib():
         fn.argtypes = args
     _LIB = handle
     return handle
+
+
+def _assert_single_hip_runtime():
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    except OSError:
+        return
+    if len(paths) > 1:
+        raise ToucanHipError(f"two HIP runtimes are mapped ({sorted(paths)}); import torch before loading libtoucan_hip.so")
 
 
 def check(rc, what=""):

@@ -40,6 +40,7 @@ class Ops:
     def __init__(self, device):
         self.lib = capi.lib()
         self.device = torch.device(device)
+        self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
 
     def stream(self):
         if self.device.type == "cuda":
@@ -69,7 +70,15 @@ class Ops:
         d.accumulate = 1 if accumulate else 0
         d.compute = COMPUTE_BF16 if use_bf16 else COMPUTE_F32
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, cw.tile_rows
-        capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
+        tm = self.timer
+        if tm is not None and tm.wants(cw, d.compute):
+            ev0, ev1 = tm.events()
+            ev0.record()
+            capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
+            ev1.record()
+            tm.add(cw, d.compute, sum(rag.lengths), ev0, ev1)
+        else:
+            capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
         return y
 
     def layernorm(self, x, y, gamma, beta, rows, c, eps=1e-12):
@@ -262,7 +271,7 @@ class AcousticEngine:
         pmax = max(pmax, 2 * cw.pmax, 256)
         ops = self.ops
         pe = _dev(packing.rel_pos_encoding(pmax), self.device)
-        rag = Ragged([2 * pmax - 1], self.device)
+        rag = Ragged.cached([2 * pmax - 1], self.device)
         cw.ptabs = [ops.conv(blk["pos"], pe, ops.empty(2 * pmax - 1, ATT), rag) for blk in cw.blocks]
         cw.pmax = pmax
 
@@ -333,8 +342,8 @@ class AcousticEngine:
         B = len(texts)
         assert duration_scaling_factor > 0
         Ls = [int(t.shape[0]) for t in texts]
-        rag_p = Ragged(Ls, dev)
-        rag_b = Ragged([B], dev)
+        rag_p = Ragged.cached(Ls, dev)
+        rag_b = Ragged.cached([B], dev)
         R = rag_p.total_rows
         text = torch.cat([t.reshape(-1, 62).to(torch.float32) for t in texts], dim=0).to(dev).contiguous()
         emb = utt_embs.to(dev, torch.float32).reshape(B, 64).contiguous()
@@ -379,7 +388,7 @@ class AcousticEngine:
         for b0, n in zip(rag_p.begins, rag_p.lengths):
             t = int(d_host[b0:b0 + n].sum())
             Ts.append(t if t > 0 else n)  # LengthRegulator.py:52-53 (all-zero utterance -> all ones)
-        rag_f = Ragged(Ts, dev, align=2)  # even begins so that the Glow squeeze is a pure re-view
+        rag_f = Ragged.cached(Ts, dev, align=2)  # even begins so that the Glow squeeze is a pure re-view
         RF = rag_f.total_rows
 
         # ---- length regulator + pitch/energy embedding (InferenceToucanTTS.py:230-235) ----
@@ -459,8 +468,7 @@ class AcousticEngine:
             if taps is not None and b in (17, 8, 0):
                 taps[f"glow_z_after_block{b}"] = x.clone()
         mel = x.view(2 * RS, 80)  # unsqueeze == re-view (glow_utils.py:43-53)
-        rag_out = Ragged([2 * n for n in rag_s.lengths], dev, begins=[2 * b for b in rag_s.begins])
-        return mel, rag_out
+        return mel, rag_s.doubled()
 
 
 class VocoderEngine:

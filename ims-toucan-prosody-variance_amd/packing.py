@@ -59,6 +59,7 @@ class ConvWeights:
         taps, cin, ctot = w_kio.shape
         self.mode = mode
         self.taps, self.dil, self.pad_left = int(taps), int(dil), int(pad_left)
+        self.algo_taps = int(taps)  # taps of the reference op (a transposed conv packed as 3 taps only has 2)
         self.cin = int(cin)
         self.cin_pad = _roundup(cin, 32)
         dual = mode != capi.MODE_LINEAR
@@ -111,7 +112,9 @@ def pack_conv_transpose(weight, bias, stride, device, bf16=False):
             if 0 <= kidx < k:
                 w_kio[j, :, r * cout:(r + 1) * cout] = w[:, :, kidx]
     b = None if bias is None else np.tile(_np(bias), s)
-    return ConvWeights(w_kio, b, capi.MODE_LINEAR, 1, 1, device, bf16)
+    cw = ConvWeights(w_kio, b, capi.MODE_LINEAR, 1, 1, device, bf16)
+    cw.algo_taps = 2
+    return cw
 
 
 def invconv_inverse(sd, prefix):

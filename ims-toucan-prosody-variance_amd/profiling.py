@@ -1,0 +1,51 @@
+"""HIP-event timing of selected conv launches on the stream they are launched on (bench.py's roofline leg).
+
+A ``ConvTimer`` is attached to an ``engine.Ops``; for every conv launch whose kernel class it selects it
+records an event pair around the launch (torch.cuda.Event on the current stream == the launch stream).
+Algorithmic work per launch = 2 * rows * cin * cout_total * taps FLOPs (each conv is
+counted once with the reference op's own tap count) and rows * (cin + cout_total) * 4 bytes of activations.
+"""
+import torch
+
+from . import capi
+
+
+def kernel_class(cw, compute):
+    dual = cw.mode != capi.MODE_LINEAR
+    return "conv1d_%s<%dx%d%s>" % ("bf16" if compute == capi.COMPUTE_BF16 else "f32", cw.tile_rows, cw.n_tile, ",dual" if dual else "")
+
+
+class ConvTimer:
+    def __init__(self, select=None):
+        self.select = select  # None: every class; else a set of class names
+        self.records = []
+        self.enabled = True
+
+    def wants(self, cw, compute):
+        return self.enabled and (self.select is None or kernel_class(cw, compute) in self.select)
+
+    def events(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def add(self, cw, compute, rows, ev0, ev1):
+        ctot = cw.cout * (2 if cw.mode != capi.MODE_LINEAR else 1)
+        flops = 2.0 * rows * cw.cin * ctot * cw.algo_taps
+        self.records.append((kernel_class(cw, compute), flops, ev0, ev1))
+
+    def summary(self):
+        """class -> dict(launches, total_ms, avg_us, flops_per_launch, tflops). Call after a device sync."""
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            s = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0))
+            s["launches"] += 1
+            s["total_ms"] += ms
+            s["flops"] += flops
+        for s in out.values():
+            s["avg_us"] = 1e3 * s["total_ms"] / s["launches"]
+            s["flops_per_launch"] = s["flops"] / s["launches"]
+            s["tflops"] = s["flops"] / (s["total_ms"] * 1e-3) / 1e12 if s["total_ms"] > 0 else 0.0
+        return out
+
+    def reset(self):
+        self.records = []

@@ -11,6 +11,19 @@ import torch
 
 
 class Ragged:
+    _cache = {}
+
+    @classmethod
+    def cached(cls, lengths, device, align=1):
+        """Layouts (and their device-side tile tables) are reused across calls with the same shape signature."""
+        key = (tuple(int(n) for n in lengths), str(device), int(align))
+        hit = cls._cache.get(key)
+        if hit is None:
+            if len(cls._cache) > 64:
+                cls._cache.clear()
+            hit = cls._cache[key] = cls(lengths, device, align)
+        return hit
+
     def __init__(self, lengths, device, align=1, begins=None):
         self.lengths = [int(n) for n in lengths]
         self.device = device
@@ -28,6 +41,7 @@ class Ragged:
         self.max_len = max(self.lengths) if self.lengths else 0
         self._tiles = {}
         self._bounds = None
+        self._derived = {}
 
     def bounds(self):
         """(seq_begin, seq_end) int32 device tensors."""
@@ -41,20 +55,34 @@ class Ragged:
         """(device int32 tensor [n,4] = (row0, seq_begin, seq_end, seq_id), n)."""
         key = int(rows_per_tile)
         if key not in self._tiles:
-            out = []
-            for u, (b, n) in enumerate(zip(self.begins, self.lengths)):
-                for r in range(0, n, key):
-                    out.append((b + r, b, b + n, u))
-            arr = np.asarray(out, dtype=np.int32).reshape(-1, 4)
-            self._tiles[key] = (torch.from_numpy(arr).to(self.device), arr.shape[0])
+            b = np.asarray(self.begins, dtype=np.int64)
+            n = np.asarray(self.lengths, dtype=np.int64)
+            per = (n + key - 1) // key  # tiles per utterance
+            sid = np.repeat(np.arange(len(n)), per)
+            first = np.cumsum(per) - per
+            k = np.arange(int(per.sum())) - np.repeat(first, per)  # tile index inside its utterance
+            arr = np.stack([b[sid] + k * key, b[sid], b[sid] + n[sid], sid], axis=1).astype(np.int32).reshape(-1, 4)
+            assert self.total_rows < 2 ** 31
+            self._tiles[key] = (torch.from_numpy(np.ascontiguousarray(arr)).to(self.device), arr.shape[0])
         return self._tiles[key]
 
     def scaled(self, factor):
         """Layout after a transposed conv of stride ``factor``: [rows, f*C] viewed as [rows*f, C]."""
-        return Ragged([n * factor for n in self.lengths], self.device, begins=[b * factor for b in self.begins])
+        key = ("scaled", factor)
+        if key not in self._derived:
+            self._derived[key] = Ragged([n * factor for n in self.lengths], self.device, begins=[b * factor for b in self.begins])
+        return self._derived[key]
 
     def halved(self):
         """Glow squeeze (glow_utils.py:28-40): pairs of frames become one row; an odd last frame is dropped.
         Requires even begins (construct the frame layout with align=2)."""
-        assert all(b % 2 == 0 for b in self.begins)
-        return Ragged([n // 2 for n in self.lengths], self.device, begins=[b // 2 for b in self.begins])
+        if "halved" not in self._derived:
+            assert all(b % 2 == 0 for b in self.begins)
+            self._derived["halved"] = Ragged([n // 2 for n in self.lengths], self.device, begins=[b // 2 for b in self.begins])
+        return self._derived["halved"]
+
+    def doubled(self):
+        """Inverse re-view of ``halved`` (glow_utils.py:43-53): every squeezed row is two frames again."""
+        if "doubled" not in self._derived:
+            self._derived["doubled"] = Ragged([2 * n for n in self.lengths], self.device, begins=[2 * b for b in self.begins])
+        return self._derived["doubled"]

@@ -1,0 +1,248 @@
+"""Kernel-level parity on a real MI355X: every entry point of libtoucan_hip.so against the numpy ABI
+emulator (tests/abi_emulator.py) on seeded random inputs, ragged batches and edge cases.
+Tolerances: fp32 kernels 2e-5 relative to the output scale (rounding order only); bf16 MFMA 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+import ims_toucan_prosody_variance_amd  # noqa: F401
+from ims_toucan_prosody_variance_amd import capi, engine, packing
+from ims_toucan_prosody_variance_amd.ragged import Ragged
+from tests import abi_emulator
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    ops = engine.Ops("cuda:0")
+    assert not isinstance(ops.lib, abi_emulator.Emulator)
+    return ops
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    ops = engine.Ops("cpu")
+    ops.lib = abi_emulator.Emulator()
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol=2e-5):
+    a, b = a.detach().cpu().float().numpy(), b.detach().cpu().float().numpy()
+    scale = max(1.0, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= tol * scale, f"max abs err {err:.3e} vs tol {tol * scale:.3e}"
+
+
+def both(gpu, cpu, fn):
+    """fn(ops, to) runs the op with tensors moved by `to`; returns output tensor(s)."""
+    out_g = fn(gpu, lambda t: t.to("cuda:0").contiguous())
+    torch.cuda.synchronize()
+    out_c = fn(cpu, lambda t: t.clone().contiguous())
+    return out_g, out_c
+
+
+CONV_CASES = [
+    # cin, cout, k, dil, mode, lengths
+    (62, 100, 1, 1, capi.MODE_LINEAR, [7, 20]),
+    (192, 1536, 1, 1, capi.MODE_LINEAR, [128, 97, 1]),
+    (1536, 192, 1, 1, capi.MODE_LINEAR, [130]),
+    (192, 576, 1, 1, capi.MODE_LINEAR, [300, 5]),
+    (192, 256, 5, 1, capi.MODE_LINEAR, [64, 3, 129]),
+    (80, 512, 7, 1, capi.MODE_LINEAR, [42, 126]),
+    (64, 64, 11, 5, capi.MODE_LINEAR, [700, 30]),
+    (32, 32, 3, 3, capi.MODE_LINEAR, [1000, 257]),
+    (256, 1, 1, 1, capi.MODE_LINEAR, [20, 7]),
+    (272, 192, 5, 1, capi.MODE_LINEAR, [88]),
+    (192, 384, 1, 1, capi.MODE_GLU, [128, 33]),
+    (192, 384, 5, 1, capi.MODE_GATED, [63, 21]),
+    (192, 160, 1, 1, capi.MODE_COUPLING, [44, 63]),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", CONV_CASES)
+@pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
+def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute):
+    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
+    b = rnd(cout, seed=2, scale=0.1).numpy()
+    dual = mode != capi.MODE_LINEAR
+    co = cout // 2 if dual else cout
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        R = rag.total_rows
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode, bf16=True)
+        x = to(rnd(R, cin + 3, seed=3))[:, :cin]  # strided input view
+        y = to(rnd(R, co + 5, seed=4))
+        res = to(rnd(R, co, seed=5))
+        pre = to(rnd(R, 2 * co if dual else co, seed=6))
+        sv = to(rnd(len(lengths), co, seed=7))
+        aux = to(rnd(R, co, seed=8)) if mode == capi.MODE_COUPLING else None
+        ops.conv(cw, x, y[:, :co], rag, pre=capi.PRE_LRELU, pre_slope=0.1, act=capi.ACT_TANH, alpha=0.5, seqvec=sv, preadd=pre, res=res,
+                 res_scale=0.25, aux=aux, accumulate=True, compute=compute)
+        return y
+
+    g, c = both(gpu, cpu, run)
+    close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
+
+
+def test_conv1d_rows_outside_utterances_are_untouched(gpu):
+    rag = Ragged([5, 3], gpu.device, align=2)  # rows 5 and 9 are alignment padding
+    cw = packing.pack_conv(rnd(32, 32, 3).numpy(), None, gpu.device)
+    x = torch.ones(rag.total_rows, 32, device="cuda")
+    y = torch.full((rag.total_rows, 32), 7.0, device="cuda")
+    gpu.conv(cw, x, y, rag)
+    torch.cuda.synchronize()
+    assert torch.all(y[5] == 7.0) and torch.all(y[9] == 7.0)
+    assert not torch.any(y[:5] == 7.0)
+
+
+@pytest.mark.parametrize("stride,k,cin,cout", [(8, 16, 512, 256), (2, 4, 64, 32)])
+def test_conv_transpose_polyphase_matches_torch_definition(gpu, stride, k, cin, cout):
+    """The 3-tap polyphase packing against the textbook ConvTranspose1d definition (fp64 on the host)."""
+    T = 37
+    w = rnd(cin, cout, k, seed=11, scale=1.0 / np.sqrt(2 * cin))
+    b = rnd(cout, seed=12, scale=0.1)
+    x = rnd(T, cin, seed=13)
+    ref = torch.nn.functional.conv_transpose1d(x.t().unsqueeze(0).double(), w.double(), b.double(), stride=stride, padding=(k - stride) // 2)[0].t()
+    cw = packing.pack_conv_transpose(w.numpy(), b.numpy(), stride, gpu.device)
+    rag = Ragged([T], gpu.device)
+    y = gpu.conv(cw, x.cuda(), gpu.empty(T, stride * cout), rag)
+    torch.cuda.synchronize()
+    close(y.view(T * stride, cout), ref.float(), 2e-5)
+
+
+def test_layernorm_cln_l2_groupnorm(gpu, cpu):
+    def ln(ops, to):
+        x = to(rnd(300, 192, seed=1))
+        return ops.layernorm(x, ops.empty(300, 192), to(rnd(192, seed=2)), to(rnd(192, seed=3)), 300, 192)
+    close(*both(gpu, cpu, ln))
+
+    def cln(ops, to):
+        rag = Ragged([70, 5, 128], ops.device)
+        x = to(rnd(rag.total_rows, 256, seed=1).abs())
+        return ops.cond_layernorm(x, ops.empty(rag.total_rows, 256), to(rnd(3, 256, seed=2)), to(rnd(3, 256, seed=3)), 256, rag)
+    close(*both(gpu, cpu, cln), tol=1e-4)
+
+    def l2(ops, to):
+        return ops.l2_normalize(to(rnd(5, 64, seed=1)), ops.empty(5, 64))
+    close(*both(gpu, cpu, l2))
+
+    for c, groups, tanh in ((256, 32, True), (80, 20, False)):
+        def gn(ops, to):
+            rag = Ragged([101, 7, 640], ops.device, align=2)
+            x = to(rnd(rag.total_rows, c, seed=1))
+            res = to(rnd(rag.total_rows, c, seed=4))
+            y = to(torch.zeros(rag.total_rows, c))
+            return ops.groupnorm(x, y, to(rnd(c, seed=2)), to(rnd(c, seed=3)), c, groups, rag, tanh=tanh, res=res)
+        close(*both(gpu, cpu, gn), tol=5e-5)
+
+
+@pytest.mark.parametrize("lengths", [[7], [64], [65, 128, 1], [640, 333]])
+def test_relpos_attention(gpu, cpu, lengths):
+    pmax = 700
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        qkv = to(rnd(rag.total_rows, 576, seed=1, scale=0.7))
+        ptab = to(rnd(2 * pmax - 1, 192, seed=2, scale=0.5))
+        ctx = to(torch.zeros(rag.total_rows, 192))
+        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag)
+    close(*both(gpu, cpu, run), tol=5e-5)
+
+
+@pytest.mark.parametrize("k", [7, 31])
+def test_dwconv_swish(gpu, cpu, k):
+    def run(ops, to):
+        rag = Ragged([100, 3, 65], ops.device, align=2)
+        x = to(rnd(rag.total_rows, 192, seed=1))
+        y = to(torch.zeros(rag.total_rows, 192))
+        return ops.dwconv_swish(x, y, to(rnd(k, 192, seed=2, scale=0.3)), to(rnd(192, seed=3, scale=0.1)), 192, k, rag)
+    close(*both(gpu, cpu, run))
+
+
+def test_duration_control_length_regulator(gpu, cpu):
+    lengths = [20, 7, 33]
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device)
+        R = rag.total_rows
+        g = torch.Generator().manual_seed(5)
+        text = to((torch.rand(R, 62, generator=g) < 0.3).float())
+        logd = to(rnd(R, seed=1, scale=0.5) + 1.6)
+        # exact .5 cases for round-half-even: exp(x)-1 = 2.5 / 3.5
+        logd[0], logd[1] = float(np.log(3.5)), float(np.log(4.5))
+        d = to(torch.zeros(R, dtype=torch.int32))
+        ops.duration_from_log(logd, d)
+        p, e = to(rnd(R, seed=2)), to(rnd(R, seed=3).abs())
+        ops.prosody_control(text, p, e, d, rag, 1.2, 1.3, 0.7, 1.2)
+        if ops.device.type == "cuda":
+            torch.cuda.synchronize()
+        dh = d.cpu().numpy()
+        Ts = [int(dh[b:b + n].sum()) for b, n in zip(rag.begins, rag.lengths)]
+        ragf = Ragged(Ts, ops.device, align=2)
+        enc = to(rnd(R, 192, seed=4))
+        up = to(torch.zeros(ragf.total_rows, 192))
+        dec = to(torch.zeros(ragf.total_rows, 192))
+        ops.length_regulate(enc, p, e, to(rnd(192, seed=6)), to(rnd(192, seed=7)), to(rnd(192, seed=8)), to(rnd(192, seed=9)), d, rag, ragf,
+                            up, dec, 13.0)
+        return torch.cat([d.float(), p, e, up.reshape(-1), dec.reshape(-1)])
+    g, c = both(gpu, cpu, run)
+    assert torch.equal(g.cpu()[: sum(lengths)], c[: sum(lengths)])  # integer durations: bit exact
+    close(g, c, 1e-5)
+
+
+def test_length_regulator_all_zero_utterance_becomes_all_ones(gpu):
+    rag = Ragged([4, 3], gpu.device)
+    d = torch.tensor([0, 0, 0, 0, 2, 0, 1], dtype=torch.int32, device="cuda")
+    ragf = Ragged([4, 3], gpu.device, align=2)
+    enc = torch.arange(7, dtype=torch.float32, device="cuda")[:, None].repeat(1, 192).contiguous()
+    z = torch.zeros(7, device="cuda")
+    zero = torch.zeros(192, device="cuda")
+    up = torch.zeros(ragf.total_rows, 192, device="cuda")
+    gpu.length_regulate(enc, z, z, zero, zero, zero, zero, d, rag, ragf, up, None, 1.0)
+    torch.cuda.synchronize()
+    assert up[:, 0].tolist() == [0, 1, 2, 3, 4, 4, 6, 0]
+
+
+def test_glow_invconv_actnorm(gpu, cpu):
+    def run(ops, to):
+        x = to(rnd(77, 160, seed=1))
+        ops.glow_invconv_actnorm(x, 77, 160, to(rnd(16, seed=2)), to(rnd(160, seed=3, scale=0.1)), to(rnd(160, seed=4, scale=0.1)))
+        return x
+    close(*both(gpu, cpu, run))
+
+
+@pytest.mark.parametrize("c,lengths", [(32, [1000, 9]), (256, [336, 1, 2, 70]), (64, [64, 8])])
+def test_snake_aa(gpu, cpu, c, lengths):
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        x = to(rnd(rag.total_rows, c, seed=1))
+        y = to(torch.zeros(rag.total_rows, c))
+        filt = to(torch.from_numpy(packing.kaiser_sinc_filter12()))
+        return ops.snake_aa(x, y, to(rnd(c, seed=2, scale=0.3)), to(rnd(c, seed=3, scale=0.3)), filt, c, rag)
+    close(*both(gpu, cpu, run), tol=2e-5)
+
+
+@pytest.mark.parametrize("pre", [capi.PRE_NONE, capi.PRE_LRELU])
+def test_conv_post(gpu, cpu, pre):
+    def run(ops, to):
+        rag = Ragged([1000, 3, 256], ops.device, align=2)
+        x = to(rnd(rag.total_rows, 32, seed=1))
+        wav = to(torch.zeros(rag.total_rows))
+        return ops.conv_post(x, 32, to(rnd(7, 32, seed=2, scale=0.1)), 0.05, pre, 0.01, wav, rag)
+    close(*both(gpu, cpu, run))
+
+
+def test_library_rejects_bad_arguments(gpu):
+    rag = Ragged([10], gpu.device)
+    cw = packing.pack_conv(rnd(32, 32, 3).numpy(), None, gpu.device)
+    cw.tile_rows = 64  # tile table built for the wrong tile height
+    with pytest.raises(capi.ToucanHipError, match="tile table"):
+        gpu.conv(cw, gpu.empty(10, 32), gpu.empty(10, 32), rag)
