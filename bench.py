@@ -33,7 +33,12 @@ def cpu_baseline(phones, frames_per_phone, vocoder):
     """The CPU oracle (kind 'port') on a bounded sample: ONE utterance of the same workload, processed the way the
     reference's read_to_file does (one utterance at a time), all host cores."""
     from oracle import toucan_oracle as orc
-    cores = os.cpu_count() or 1
+    # the GPU box exposes many more logical CPUs than its cgroup share (16 per GPU): oversubscribing stalls torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     oa = orc.AcousticOracle(fw.acoustic_state_dict())
     ov = orc.VocoderOracle(fw.bigvgan_state_dict() if vocoder == "bigvgan" else fw.hifigan_state_dict(), vocoder)
@@ -61,6 +66,11 @@ def cpu_baseline(phones, frames_per_phone, vocoder):
                 e2e_rtf=(ta + tv) / (w.numel() / 24000.0))
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,11 +95,13 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     bf16 = args.dtype == "bf16"
+    log("building engines (fixture weights)")
     ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev)
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
     voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, bf16=bf16)
 
     B, L, T = args.batch, args.phones, args.phones * args.frames_per_phone
+    log(f"synthetic inputs: {B} x {L} phonemes -> {T} frames per utterance")
     ids = [rank * B + u for u in range(B)]
     texts = [torch.from_numpy(syn.utterance_features(u, L, word_boundaries=False)).to(dev) for u in ids]
     embs = torch.from_numpy(np.stack([syn.utterance_embedding(u) for u in ids])).to(dev)
@@ -116,8 +128,10 @@ def main():
     # ---- warm-up; the first warm-up step times every conv class to find the dominant kernel ----
     timer = profiling.ConvTimer()
     ac.ops.timer = voc.ops.timer = timer
+    log("warm-up step 1 (all conv classes timed)")
     step()
     torch.cuda.synchronize()
+    log("warm-up step 1 done")
     classes = timer.summary()
     dominant = max(classes, key=lambda k: classes[k]["total_ms"])
     ac.ops.timer = voc.ops.timer = None
@@ -131,7 +145,8 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     t_ac = t_voc = 0.0
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        log(f"timed step {it}")
         out, wav = step(record=True)
         ev[2].synchronize()
         t_ac += ev[0].elapsed_time(ev[1]) * 1e-3
@@ -172,7 +187,9 @@ def main():
             "kernel_classes_first_step": {k: {"ms": round(v["total_ms"], 3), "launches": v["launches"], "tflops": round(v["tflops"], 2)}
                                           for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["total_ms"])},
         }
+        log(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms/step")
         if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle, one utterance)")
             line["cpu_baseline"] = cpu_baseline(L, args.frames_per_phone, args.vocoder)
         print(json.dumps(line))
     if world > 1:
