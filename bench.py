@@ -96,7 +96,7 @@ def main():
 
     bf16 = args.dtype == "bf16"
     log("building engines (fixture weights)")
-    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev)
+    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, bf16=bf16)
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
     voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, bf16=bf16)
 
@@ -176,7 +176,7 @@ def main():
             "config": {"workload": f"configs[2]: batch={B}/GPU x {L} phonemes -> {T} frames, acoustic (PostFlow on) + {args.vocoder}, "
                                    f"gold durations {args.frames_per_phone}/phoneme, fixture weights",
                        "global_batch": world * B, "phones": L, "frames_per_utt": frames_out // B, "vocoder": args.vocoder,
-                       "acoustic_dtype": "f32", "vocoder_dtype": "bf16" if bf16 else "f32", "parallelism": f"dp{world}"},
+                       "acoustic_dtype": "bf16 MFMA / f32 activations" if bf16 else "f32", "vocoder_dtype": "bf16" if bf16 else "f32", "parallelism": f"dp{world}"},
             "acoustic_mel_frames_per_s": world * frames_out * args.steps / t_ac,
             "vocoder_rtf": t_voc / (args.steps * audio_s),
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),

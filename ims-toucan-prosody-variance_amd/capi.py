@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libtoucan_hip.so")
 
 MODE_LINEAR, MODE_GLU, MODE_GATED, MODE_COUPLING = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
-PRE_NONE, PRE_LRELU = 0, 1
+PRE_NONE, PRE_LRELU, PRE_SNAKE = 0, 1, 2
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
 
 _p = C.c_void_p
@@ -31,6 +31,7 @@ class TtsConvDesc(C.Structure):
         ("y", _p), ("ldy", _i), ("cout", _i),
         ("taps", _i), ("dil", _i), ("pad_left", _i),
         ("pre_act", _i), ("pre_slope", _f),
+        ("snake_alpha", _p), ("snake_beta", _p), ("snake_filt", _p),
         ("mode", _i), ("act", _i), ("alpha", _f),
         ("seqvec", _p), ("ld_seqvec", _i),
         ("preadd", _p), ("ld_preadd", _i),

@@ -16,6 +16,7 @@
 //
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
 #include "common.h"
+#include "snake.h"
 
 namespace tts {
 
@@ -77,7 +78,25 @@ __global__ __launch_bounds__(256) void conv1d_f32_kernel(const TtsConvDesc d) {
     const int c0 = ch * BK;
     __syncthreads();  // previous chunk's readers are done with xs
     // ---- stage the activation window: win_rows x 32 channels ----
-    if (vec_ok) {
+    if (d.pre_act == TTS_PRE_SNAKE) {
+      // anti-aliased snake computed while staging: item = (8 window rows, channel); the activated tensor never reaches HBM
+      float f[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) f[k] = d.snake_filt[k];
+      const int T = tile.seq_end - tile.seq_begin;
+      const int items = ((win_rows + 7) >> 3) * BK;
+      for (int it = tid; it < items; it += 256) {
+        const int chl = it & 31, wr0 = (it >> 5) * 8;
+        const int cg = c0 + chl;
+        const int t0 = row_first + wr0 - tile.seq_begin;  // local frame of the group's first row (may be < 0)
+        float o[8];
+        const bool live = cg < d.cin && t0 + 7 >= 0 && t0 < T;
+        if (live) snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, expf(d.snake_alpha[cg]), 1.0f / (expf(d.snake_beta[cg]) + 1e-9f), o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (wr0 + i < win_rows) xs[(wr0 + i) * XP + chl] = (live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f;
+      }
+    } else if (vec_ok) {
       for (int e = tid; e < win_rows * (BK / 4); e += 256) {
         const int wr = e >> 3, c4 = (e & 7) * 4;
         const int gr = row_first + wr;
@@ -226,7 +245,24 @@ __global__ __launch_bounds__(256) void conv1d_bf16_kernel(const TtsConvDesc d) {
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int c0 = ch * BK;
     __syncthreads();
-    if (vec_ok) {
+    if (d.pre_act == TTS_PRE_SNAKE) {
+      float f[12];
+#pragma unroll
+      for (int k = 0; k < 12; ++k) f[k] = d.snake_filt[k];
+      const int T = tile.seq_end - tile.seq_begin;
+      const int items = ((win_rows + 7) >> 3) * BK;
+      for (int it = tid; it < items; it += 256) {
+        const int chl = it & 31, wr0 = (it >> 5) * 8;
+        const int cg = c0 + chl;
+        const int t0 = row_first + wr0 - tile.seq_begin;
+        float o[8];
+        const bool live = cg < d.cin && t0 + 7 >= 0 && t0 < T;
+        if (live) snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, expf(d.snake_alpha[cg]), 1.0f / (expf(d.snake_beta[cg]) + 1e-9f), o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (wr0 + i < win_rows) xs[(wr0 + i) * XPB + chl] = f2bf((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
+      }
+    } else if (vec_ok) {
       for (int e = tid; e < win_rows * (BK / 4); e += 256) {
         const int wr = e >> 3, c4 = (e & 7) * 4;
         const int gr = row_first + wr;
@@ -377,6 +413,7 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.cin_pad % 32 == 0 && d.cin_pad >= d.cin, "conv1d: cin_pad %d must be a multiple of 32 >= cin %d", d.cin_pad, d.cin);
   TTS_CHECK_ARG(d.mode >= 0 && d.mode <= 3, "conv1d: bad mode %d", d.mode);
   TTS_CHECK_ARG(d.mode != TTS_MODE_COUPLING || d.aux, "conv1d: coupling mode needs aux");
+  TTS_CHECK_ARG(d.pre_act != TTS_PRE_SNAKE || (d.snake_alpha && d.snake_beta && d.snake_filt), "conv1d: PRE_SNAKE needs alpha/beta/filter");
   if (d.n_tiles == 0) return TTS_OK;
   const ConvShape s = pick_shape(d.cout, d.mode);
   int bm, bn;

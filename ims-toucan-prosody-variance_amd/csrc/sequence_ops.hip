@@ -3,6 +3,7 @@
 // contiguous in memory, so a wavefront touches whole 256-B segments), sliding windows live in registers
 // (static unrolling), halos are resolved per utterance through the tile table.
 #include "common.h"
+#include "snake.h"
 
 namespace tts {
 
@@ -264,16 +265,6 @@ int glow_invconv_actnorm(float* x, int ldx, int rows, int c, const float* winv, 
 // Each thread: one channel x ROWS consecutive frames; the 2x-rate signal exists only in registers
 // (2*ROWS+10 values), so the up-sampled tensor never touches LDS or HBM.
 // ------------------------------------------------------------------------------------------------
-// sin^2(a) with one hardware sine: a/(2*pi) is reduced to [-0.5, 0.5] revolutions, v_sin_f32 takes revolutions.
-// Absolute error of the squared sine ~1e-6 for |a| up to a few hundred radians (measured against the fp64 emulator
-// in tests/test_gpu_kernels.py::test_snake_aa), versus ~1e-7 for ocml's sinf at 5x the cost and 187 VGPRs.
-__device__ __forceinline__ float sin_sq(float a) {
-  float t = a * 0.15915494309189535f;
-  t -= rintf(t);
-  const float sn = __builtin_amdgcn_sinf(t);
-  return sn * sn;
-}
-
 template <int ROWS>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
@@ -281,7 +272,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
                                                        int tile_rows) {
   const TtsTile t = tiles[blockIdx.x];
   // work item = (group of ROWS frames, channel); consecutive threads take consecutive channels, so a wavefront
-  // reads 256 contiguous bytes per row (two 128-byte rows when c == 32)
+  // reads 256 contiguous bytes per row (two 128-byte rows when c == 32).  The 2x-rate signal lives in registers only.
   const int item = blockIdx.y * 256 + threadIdx.x;
   const int ch = item % c;
   const int g = item / c;
@@ -291,56 +282,14 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
   float f[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) f[k] = filt[k];
-  const float ea = __expf(alpha[ch]);
-  const float inv_b = 1.0f / (__expf(beta[ch]) + 1e-9f);
-  const int T = t.seq_end - t.seq_begin;
-  constexpr int NX = ROWS + 12, NS = 2 * ROWS + 10;
-  const int t0 = r0 - t.seq_begin;  // local frame index
-  float xin[NX];                    // x[t0-6 .. t0+ROWS+5], replicate padded inside the utterance
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    int q = t0 - 6 + i;
-    q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
-    xin[i] = x[(size_t)(t.seq_begin + q) * ldx + ch];
-  }
-  float s[NS];  // s[m] <-> n = 2*t0 - 5 + m
-#pragma unroll
-  for (int m = 0; m < NS; ++m) {
-    // n = 2*t0 - 5 + m;  q = floor(n/2) = t0 - 3 + ((m+1)>>1);  xin index of x[q+d] = 3 + ((m+1)>>1) + d
-    const int qi = 3 + ((m + 1) >> 1);
-    float u = 0.f;
-    if (((m + 1) & 1) == 0) {  // n even (m odd): taps f[5-2d], d = -3..2
-#pragma unroll
-      for (int d = -3; d <= 2; ++d) u = fmaf(xin[qi + d], f[5 - 2 * d], u);
-    } else {  // n odd: taps f[6-2d], d = -2..3
-#pragma unroll
-      for (int d = -2; d <= 3; ++d) u = fmaf(xin[qi + d], f[6 - 2 * d], u);
-    }
-    u *= 2.0f;
-    s[m] = fmaf(inv_b, sin_sq(u * ea), u);
-  }
-  // replicate padding of the 2x-rate signal: positions n < 0 take s[n=0], n > 2T-1 take s[n=2T-1]
-  const int nbase = 2 * t0 - 5;
-  if (nbase < 0 || nbase + NS - 1 > 2 * T - 1) {
-    float s_lo = 0.f, s_hi = 0.f;
-#pragma unroll
-    for (int m = 0; m < NS; ++m) {
-      if (nbase + m == 0) s_lo = s[m];
-      if (nbase + m == 2 * T - 1) s_hi = s[m];
-    }
-#pragma unroll
-    for (int m = 0; m < NS; ++m) {
-      if (nbase + m < 0) s[m] = s_lo;
-      if (nbase + m > 2 * T - 1) s[m] = s_hi;
-    }
-  }
+  const float ea = expf(alpha[ch]);
+  const float inv_b = 1.0f / (expf(beta[ch]) + 1e-9f);
+  float out[ROWS];
+  snake_rows<ROWS>(x, ldx, ch, t.seq_begin, t.seq_end - t.seq_begin, r0 - t.seq_begin, f, ea, inv_b, out);
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
     if (r0 + i >= t.seq_end) break;
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
-    y[(size_t)(r0 + i) * ldy + ch] = a;
+    y[(size_t)(r0 + i) * ldy + ch] = out[i];
   }
 }
 

@@ -1,0 +1,77 @@
+// Anti-aliased SnakeBeta on ROWS consecutive frames of one channel, entirely in registers.
+// (BigVGAN/Snake.py:56-69 inside alias_free_torch's Activation1d - third party, PARITY UNPINNED, restated from its
+// published algorithm):
+//   u[2q]   = 2 * sum_{d=-3..2} x[q+d] f[5-2d]      u[2q+1] = 2 * sum_{d=-2..3} x[q+d] f[6-2d]   (x replicate padded)
+//   s[n]    = u[n] + sin^2(u[n] * e^alpha) / (e^beta + 1e-9)
+//   y[t]    = sum_{k=0..11} s[clamp(2t + k - 5, 0, 2T-1)] f[k]
+// Shared by the stand-alone kernel (sequence_ops.hip) and the conv input staging (conv1d.hip, TTS_PRE_SNAKE).
+#pragma once
+#include "common.h"
+
+namespace tts {
+
+// sin^2(a) with one hardware sine: a/(2*pi) is reduced to [-0.5, 0.5] revolutions, v_sin_f32 takes revolutions.
+// Absolute error ~1e-6 for |a| up to a few hundred radians (tests/test_gpu_kernels.py::test_snake_aa checks it against
+// the fp64 emulator), versus ~1e-7 for ocml's sinf at 5x the cost and 3x the registers.
+__device__ __forceinline__ float sin_sq(float a) {
+  float t = a * 0.15915494309189535f;
+  t -= rintf(t);
+  const float sn = __builtin_amdgcn_sinf(t);
+  return sn * sn;
+}
+
+// out[i] = snake_aa(x)[t0 + i] for i < ROWS; t0 is the local frame index inside an utterance of T frames whose first
+// packed row is seq_begin.  t0 may be negative / rows may lie beyond T: those outputs are meaningless (callers mask
+// them), but every output with 0 <= t0+i < T is exact provided the group overlaps [0, T).
+template <int ROWS>
+__device__ __forceinline__ void snake_rows(const float* __restrict__ x, int ldx, int ch, int seq_begin, int T, int t0,
+                                           const float (&f)[12], float ea, float inv_b, float (&out)[ROWS]) {
+  constexpr int NX = ROWS + 12, NS = 2 * ROWS + 10;
+  float xin[NX];  // x[t0-6 .. t0+ROWS+5], replicate padded inside the utterance
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    int q = t0 - 6 + i;
+    q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
+    xin[i] = x[(size_t)(seq_begin + q) * ldx + ch];
+  }
+  float s[NS];  // s[m] <-> n = 2*t0 - 5 + m
+#pragma unroll
+  for (int m = 0; m < NS; ++m) {
+    // q = floor(n/2) = t0 - 3 + ((m+1)>>1);  xin index of x[q+d] = 3 + ((m+1)>>1) + d
+    const int qi = 3 + ((m + 1) >> 1);
+    float u = 0.f;
+    if (((m + 1) & 1) == 0) {  // n even (m odd): taps f[5-2d], d = -3..2
+#pragma unroll
+      for (int d = -3; d <= 2; ++d) u = fmaf(xin[qi + d], f[5 - 2 * d], u);
+    } else {  // n odd: taps f[6-2d], d = -2..3
+#pragma unroll
+      for (int d = -2; d <= 3; ++d) u = fmaf(xin[qi + d], f[6 - 2 * d], u);
+    }
+    u *= 2.0f;
+    s[m] = fmaf(inv_b, sin_sq(u * ea), u);
+  }
+  // replicate padding of the 2x-rate signal: positions n < 0 take s[n=0], n > 2T-1 take s[n=2T-1]
+  const int nbase = 2 * t0 - 5;
+  if (nbase < 0 || nbase + NS - 1 > 2 * T - 1) {
+    float s_lo = 0.f, s_hi = 0.f;
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      if (nbase + m == 0) s_lo = s[m];
+      if (nbase + m == 2 * T - 1) s_hi = s[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      if (nbase + m < 0) s[m] = s_lo;
+      if (nbase + m > 2 * T - 1) s[m] = s_hi;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
+    out[i] = a;
+  }
+}
+
+}  // namespace tts

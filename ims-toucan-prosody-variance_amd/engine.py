@@ -15,7 +15,7 @@ import torch
 
 from . import capi, packing
 from .capi import (ACT_NONE, ACT_RELU, ACT_TANH, COMPUTE_BF16, COMPUTE_F32, MODE_COUPLING, MODE_GATED, MODE_GLU, MODE_LINEAR,
-                   PRE_LRELU, PRE_NONE)
+                   PRE_LRELU, PRE_NONE, PRE_SNAKE)
 from .ragged import Ragged
 
 ATT, HEADS, DK = 192, 4, 48
@@ -41,6 +41,7 @@ class Ops:
         self.lib = capi.lib()
         self.device = torch.device(device)
         self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
+        self.default_compute = COMPUTE_F32  # convs whose weights carry a bf16 copy run on bf16 MFMA when this is COMPUTE_BF16
 
     def stream(self):
         if self.device.type == "cuda":
@@ -51,7 +52,9 @@ class Ops:
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
     def conv(self, cw, x, y, rag, pre=PRE_NONE, pre_slope=0.0, act=ACT_NONE, alpha=1.0, seqvec=None, preadd=None, res=None,
-             res_scale=1.0, aux=None, accumulate=False, compute=COMPUTE_F32):
+             res_scale=1.0, aux=None, accumulate=False, compute=None, snake=None):
+        if compute is None:
+            compute = self.default_compute
         tiles, n_tiles = rag.tiles(cw.tile_rows)
         d = capi.TtsConvDesc()
         d.x, d.ldx, d.cin = x.data_ptr(), _ld(x), cw.cin
@@ -62,6 +65,8 @@ class Ops:
         d.y, d.ldy, d.cout = y.data_ptr(), _ld(y), cw.cout
         d.taps, d.dil, d.pad_left = cw.taps, cw.dil, cw.pad_left
         d.pre_act, d.pre_slope = pre, pre_slope
+        if snake is not None:  # (alpha[cin], beta[cin], filter[12]) for PRE_SNAKE
+            d.snake_alpha, d.snake_beta, d.snake_filt = snake[0].data_ptr(), snake[1].data_ptr(), snake[2].data_ptr()
         d.mode, d.act, d.alpha = cw.mode, act, alpha
         d.seqvec, d.ld_seqvec = _ptr(seqvec), _ld(seqvec)
         d.preadd, d.ld_preadd = _ptr(preadd), _ld(preadd)
@@ -163,27 +168,28 @@ def _dev(a, device):
 class ConformerWeights:
     """Packed weights of one Layers/Conformer.py stack (6 EncoderLayers)."""
 
-    def __init__(self, sd, prefix, kernel, device):
+    def __init__(self, sd, prefix, kernel, device, bf16=False):
         self.kernel = kernel
         self.blocks = []
+        pack = lambda *a, **k: packing.pack_conv(*a, bf16=bf16, **k)
         for b in range(6):
             p = f"{prefix}.encoders.{b}."
             blk = {}
             for ln in ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final"):
                 blk[ln] = (_dev(sd[p + ln + ".weight"], device), _dev(sd[p + ln + ".bias"], device))
             for ff in ("feed_forward_macaron", "feed_forward"):
-                blk[ff + ".w1"] = packing.pack_conv(sd[p + ff + ".w_1.weight"], sd[p + ff + ".w_1.bias"], device)
-                blk[ff + ".w2"] = packing.pack_conv(sd[p + ff + ".w_2.weight"], sd[p + ff + ".w_2.bias"], device)
+                blk[ff + ".w1"] = pack(sd[p + ff + ".w_1.weight"], sd[p + ff + ".w_1.bias"], device)
+                blk[ff + ".w2"] = pack(sd[p + ff + ".w_2.weight"], sd[p + ff + ".w_2.bias"], device)
             a = p + "self_attn."
             wqkv = np.concatenate([sd[a + f"linear_{n}.weight"] for n in "qkv"], axis=0)
             bqkv = np.concatenate([sd[a + f"linear_{n}.bias"] for n in "qkv"], axis=0)
-            blk["qkv"] = packing.pack_conv(wqkv, bqkv, device)
-            blk["out"] = packing.pack_conv(sd[a + "linear_out.weight"], sd[a + "linear_out.bias"], device)
-            blk["pos"] = packing.pack_conv(sd[a + "linear_pos.weight"], None, device)
+            blk["qkv"] = pack(wqkv, bqkv, device)
+            blk["out"] = pack(sd[a + "linear_out.weight"], sd[a + "linear_out.bias"], device)
+            blk["pos"] = packing.pack_conv(sd[a + "linear_pos.weight"], None, device)  # table built once, fp32
             blk["u"] = _dev(sd[a + "pos_bias_u"].reshape(-1), device)
             blk["v"] = _dev(sd[a + "pos_bias_v"].reshape(-1), device)
             c = p + "conv_module."
-            blk["pw1"] = packing.pack_conv(sd[c + "pointwise_conv1.weight"], sd[c + "pointwise_conv1.bias"], device, mode=MODE_GLU)
+            blk["pw1"] = pack(sd[c + "pointwise_conv1.weight"], sd[c + "pointwise_conv1.bias"], device, mode=MODE_GLU)
             # BatchNorm1d eval (running stats, eps 1e-5) folded into the depthwise conv: Convolution.py:26-27,50-51
             g = sd[c + "norm.weight"].astype(np.float64) / np.sqrt(sd[c + "norm.running_var"].astype(np.float64) + 1e-5)
             dw = sd[c + "depthwise_conv.weight"][:, 0, :].astype(np.float64) * g[:, None]  # [c, k]
@@ -191,7 +197,7 @@ class ConformerWeights:
                 + sd[c + "norm.bias"].astype(np.float64)
             blk["dw_w"] = _dev(dw.T, device)  # [k][c]
             blk["dw_b"] = _dev(db, device)
-            blk["pw2"] = packing.pack_conv(sd[c + "pointwise_conv2.weight"], sd[c + "pointwise_conv2.bias"], device)
+            blk["pw2"] = pack(sd[c + "pointwise_conv2.weight"], sd[c + "pointwise_conv2.bias"], device)
             self.blocks.append(blk)
         self.pmax = 0
         self.ptabs = None
@@ -200,24 +206,30 @@ class ConformerWeights:
 class AcousticEngine:
     """InferenceToucanTTS.ToucanTTS (:16-319) for a ragged batch of utterances."""
 
-    def __init__(self, state_dict, device):
+    def __init__(self, state_dict, device, bf16=False):
+        """bf16=True: Conformer / PostNet / PostFlow GEMMs on bf16 MFMA with fp32 accumulation and fp32 activations
+        (BASELINE.json configs[2]); the variance predictors, all norms, softmax and the flow state stay fp32."""
         self.ops = Ops(device)
         self.device = self.ops.device
+        self.bf16 = bf16
+        if bf16:
+            self.ops.default_compute = COMPUTE_BF16
         dev = self.device
         sd = packing.fold_weight_norm(state_dict)
         self.multilingual = "encoder.language_embedding.weight" in sd
         self.multispeaker = "encoder.hs_emb_projection.weight" in sd
         if not self.multispeaker:
             raise NotImplementedError("single-speaker checkpoints (LayerNorm predictors) are not supported by the HIP path yet")
-        pc = packing.pack_conv
+        pc = packing.pack_conv  # fp32 only (embedding, predictors, per-utterance vectors)
+        pcb = lambda *a, **k: packing.pack_conv(*a, bf16=bf16, **k)
         self.embed0 = pc(sd["encoder.embed.0.weight"], sd["encoder.embed.0.bias"], dev)
         self.embed2 = pc(sd["encoder.embed.2.weight"], sd["encoder.embed.2.bias"], dev)
         self.lang_table = _dev(sd["encoder.language_embedding.weight"], dev) if self.multilingual else None
-        self.enc = ConformerWeights(sd, "encoder", 7, dev)
-        self.dec = ConformerWeights(sd, "decoder", 31, dev)
+        self.enc = ConformerWeights(sd, "encoder", 7, dev, bf16)
+        self.dec = ConformerWeights(sd, "decoder", 31, dev, bf16)
         self.out_norm = (_dev(sd["encoder.output_norm.weight"], dev), _dev(sd["encoder.output_norm.bias"], dev))
         hs = sd["encoder.hs_emb_projection.weight"]
-        self.hs_h = pc(hs[:, :ATT], None, dev)  # acts on the hidden states
+        self.hs_h = pcb(hs[:, :ATT], None, dev)  # acts on the hidden states
         self.hs_e = pc(hs[:, ATT:], sd["encoder.hs_emb_projection.bias"], dev)  # acts on the utterance embedding (+ bias)
         self.pred = {}
         for name, layers, k in (("pitch_predictor", 7, 5), ("energy_predictor", 2, 3), ("duration_predictor", 3, 3)):
@@ -235,30 +247,30 @@ class AcousticEngine:
         self.pitch_b = _dev(sd["pitch_embed.0.bias"], dev)
         self.energy_w = _dev(sd["energy_embed.0.weight"].reshape(-1), dev)
         self.energy_b = _dev(sd["energy_embed.0.bias"], dev)
-        self.feat_out = pc(sd["feat_out.weight"], sd["feat_out.bias"], dev)
-        self.postnet = [(pc(sd[f"conv_postnet.postnet.{i}.0.weight"], None, dev), _dev(sd[f"conv_postnet.postnet.{i}.1.weight"], dev),
+        self.feat_out = pcb(sd["feat_out.weight"], sd["feat_out.bias"], dev)
+        self.postnet = [(pcb(sd[f"conv_postnet.postnet.{i}.0.weight"], None, dev), _dev(sd[f"conv_postnet.postnet.{i}.1.weight"], dev),
                          _dev(sd[f"conv_postnet.postnet.{i}.1.bias"], dev)) for i in range(5)]
         # PostFlow
-        self.g_proj = pc(sd["post_flow.g_proj.weight"], sd["post_flow.g_proj.bias"], dev)
+        self.g_proj = pcb(sd["post_flow.g_proj.weight"], sd["post_flow.g_proj.bias"], dev)
         self.flow = []
         for b in range(18):
             pa, pn, pcp = (f"post_flow.flows.{3 * b + i}." for i in range(3))
             blk = dict(an_bias=_dev(sd[pa + "bias"].reshape(-1), dev), an_logs=_dev(sd[pa + "logs"].reshape(-1), dev),
                        winv=_dev(packing.invconv_inverse(sd, pn), dev),
-                       start=pc(sd[pcp + "start.weight"], sd[pcp + "start.bias"], dev),
-                       end=pc(sd[pcp + "end.weight"], sd[pcp + "end.bias"], dev, mode=MODE_COUPLING),
-                       cond=pc(sd[pcp + "wn.cond_layer.weight"], sd[pcp + "wn.cond_layer.bias"], dev))
+                       start=pcb(sd[pcp + "start.weight"], sd[pcp + "start.bias"], dev),
+                       end=pc(sd[pcp + "end.weight"], sd[pcp + "end.bias"], dev, mode=MODE_COUPLING),  # m, logs: keep fp32
+                       cond=pcb(sd[pcp + "wn.cond_layer.weight"], sd[pcp + "wn.cond_layer.bias"], dev))
             if b % 4 == 0 or not self.flow:  # in/res-skip layers are shared inside groups of 4 blocks (Glow.py:325-327)
                 shared = dict(inl=[], res=[], skip=[])
                 for i in range(4):
-                    shared["inl"].append(pc(sd[pcp + f"wn.in_layers.{i}.weight"], sd[pcp + f"wn.in_layers.{i}.bias"], dev, mode=MODE_GATED))
+                    shared["inl"].append(pcb(sd[pcp + f"wn.in_layers.{i}.weight"], sd[pcp + f"wn.in_layers.{i}.bias"], dev, mode=MODE_GATED))
                     rw, rb = sd[pcp + f"wn.res_skip_layers.{i}.weight"], sd[pcp + f"wn.res_skip_layers.{i}.bias"]
                     if i < 3:  # first half feeds the residual stream, second half the skip sum (wavenet.py:112-118)
-                        shared["res"].append(pc(rw[:ATT], rb[:ATT], dev))
-                        shared["skip"].append(pc(rw[ATT:], rb[ATT:], dev))
+                        shared["res"].append(pcb(rw[:ATT], rb[:ATT], dev))
+                        shared["skip"].append(pcb(rw[ATT:], rb[ATT:], dev))
                     else:
                         shared["res"].append(None)
-                        shared["skip"].append(pc(rw, rb, dev))
+                        shared["skip"].append(pcb(rw, rb, dev))
             blk.update(shared)
             self.flow.append(blk)
         self._pe_cache = {}
@@ -478,9 +490,10 @@ class VocoderEngine:
     KS = (3, 7, 11)
     DIL = (1, 3, 5)
 
-    def __init__(self, state_dict, kind, device, bf16=False):
+    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=True):
         assert kind in ("bigvgan", "hifigan")
         self.kind = kind
+        self.fuse_snake = fuse_snake  # BigVGAN: anti-aliased snake inside the convs' input staging (no extra HBM round trip)
         self.ops = Ops(device)
         self.device = self.ops.device
         self.compute = COMPUTE_BF16 if bf16 else COMPUTE_F32
@@ -531,29 +544,34 @@ class VocoderEngine:
             R, rag = R * u, rag.scaled(u)
             xs = y.view(R, ch)
             stage_out = ops.empty(R, ch)
-            t1, t2, sa = ops.empty(R, ch), ops.empty(R, ch), (ops.empty(R, ch) if big else None)
+            t1 = ops.empty(R, ch)
+            t2, sa = (ops.empty(R, ch), ops.empty(R, ch)) if (big and not self.fuse_snake) else (None, None)
             for j in range(3):
                 cur = xs
                 bufs = [ops.empty(R, ch), ops.empty(R, ch)]
                 for dd in range(3):
                     c1, c2 = self.blocks[i][j][dd]
                     last = dd == 2
-                    if big:  # AMP.py:51-60: a1 -> c1 -> a2 -> c2 -> + x
+                    if big:  # AMP.py:51-60: a1 -> c1 -> a2 -> c2 -> + x; both activations run inside the convs' input staging
                         (a1, b1), (a2, b2) = self.snakes[i][j][dd]
-                        ops.snake_aa(cur, sa, a1, b1, self.filt, ch, rag)
-                        ops.conv(c1, sa, t1, rag, compute=cp)
-                        ops.snake_aa(t1, t2, a2, b2, self.filt, ch, rag)
-                        src2, pre2 = t2, PRE_NONE
+                        if self.fuse_snake:
+                            ops.conv(c1, cur, t1, rag, pre=PRE_SNAKE, snake=(a1, b1, self.filt), compute=cp)
+                            src2, pre2, sn2 = t1, PRE_SNAKE, (a2, b2, self.filt)
+                        else:
+                            ops.snake_aa(cur, sa, a1, b1, self.filt, ch, rag)
+                            ops.conv(c1, sa, t1, rag, compute=cp)
+                            ops.snake_aa(t1, t2, a2, b2, self.filt, ch, rag)
+                            src2, pre2, sn2 = t2, PRE_NONE, None
                     else:  # ResidualBlock.py:83-98 with LeakyReLU(0.1)
                         ops.conv(c1, cur, t1, rag, pre=PRE_LRELU, pre_slope=0.1, compute=cp)
-                        src2, pre2 = t1, PRE_LRELU
+                        src2, pre2, sn2 = t1, PRE_LRELU, None
                     if not last:
                         nxt = bufs[dd % 2]
-                        ops.conv(c2, src2, nxt, rag, pre=pre2, pre_slope=0.1, res=cur, compute=cp)
+                        ops.conv(c2, src2, nxt, rag, pre=pre2, pre_slope=0.1, snake=sn2, res=cur, compute=cp)
                         cur = nxt
                     else:  # stage output = mean of the three blocks (InferenceBigVGAN.py:82-88)
-                        ops.conv(c2, src2, stage_out, rag, pre=pre2, pre_slope=0.1, alpha=1.0 / 3.0, res=cur, res_scale=1.0 / 3.0,
-                                 accumulate=(j > 0), compute=cp)
+                        ops.conv(c2, src2, stage_out, rag, pre=pre2, pre_slope=0.1, snake=sn2, alpha=1.0 / 3.0, res=cur,
+                                 res_scale=1.0 / 3.0, accumulate=(j > 0), compute=cp)
             x = stage_out
             if taps is not None:
                 taps[f"voc_stage{i}"] = x.clone()

@@ -51,6 +51,7 @@ typedef struct {
 #define TTS_ACT_TANH 2
 #define TTS_PRE_NONE 0
 #define TTS_PRE_LRELU 1
+#define TTS_PRE_SNAKE 2 /* anti-aliased SnakeBeta (see tts_snake_aa) applied while the input window is staged */
 
 /*
  * Dense 1-D convolution over the packed time axis as an implicit GEMM on the matrix cores:
@@ -72,6 +73,7 @@ typedef struct {
   float* y;            int32_t ldy;  int32_t cout;
   int32_t taps, dil, pad_left;
   int32_t pre_act;     float pre_slope;
+  const float* snake_alpha; const float* snake_beta; const float* snake_filt; /* TTS_PRE_SNAKE: [cin], [cin], [12] */
   int32_t mode, act;   float alpha;
   const float* seqvec; int32_t ld_seqvec; /* per-utterance addend [n_seq, cout] or NULL */
   const float* preadd; int32_t ld_preadd; /* per-row addend (dual: g half at +cout) or NULL */

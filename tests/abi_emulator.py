@@ -51,6 +51,22 @@ def _bf16_round(a):
     return r.astype(np.uint32).view(np.float32)
 
 
+def _snake_seq(X, alpha, beta, filt):
+    """Activation1d(SnakeBeta) on one utterance X [T, c] (fp64): replicate pad, 2x transposed conv, snake, 2x decimation."""
+    T, c = X.shape
+    f = filt.astype(np.float64)
+    ea = np.exp(alpha.astype(np.float64))
+    ib = 1.0 / (np.exp(beta.astype(np.float64)) + 1e-9)
+    xp = np.concatenate([np.repeat(X[:1], 5, 0), X, np.repeat(X[-1:], 5, 0)], 0)  # replicate pad 5/5
+    full = np.zeros((2 * (T + 10) + 10, c))
+    for m in range(T + 10):  # conv_transpose1d stride 2
+        full[2 * m:2 * m + 12] += xp[m][None, :] * f[:, None]
+    u = 2.0 * full[15:15 + 2 * T]
+    s = u + ib * np.sin(u * ea) ** 2
+    sp = np.concatenate([np.repeat(s[:1], 5, 0), s, np.repeat(s[-1:], 6, 0)], 0)
+    return np.stack([(sp[2 * t:2 * t + 12] * f[:, None]).sum(0) for t in range(T)], 0)
+
+
 class Emulator:
     def __init__(self):
         self._real = None
@@ -95,6 +111,9 @@ class Emulator:
             x = _mat(d.x, se, d.cin, d.ldx)[sb:se].astype(np.float32)
             if d.pre_act == capi.PRE_LRELU:
                 x = np.where(x > 0, x, x * np.float32(d.pre_slope))
+            elif d.pre_act == capi.PRE_SNAKE:
+                x = _snake_seq(x.astype(np.float64), _arr(d.snake_alpha, d.cin), _arr(d.snake_beta, d.cin),
+                               _arr(d.snake_filt, 12)).astype(np.float32)
             if d.compute == capi.COMPUTE_BF16:
                 x = _bf16_round(x)
             halo = (d.taps - 1) * d.dil
@@ -281,21 +300,9 @@ class Emulator:
 
     def tts_snake_aa(self, x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, stream):
         self._count("snake_aa")
-        f = _arr(filt, 12).astype(np.float64)
-        ea = np.exp(_arr(alpha, c).astype(np.float64))
-        ib = 1.0 / (np.exp(_arr(beta, c).astype(np.float64)) + 1e-9)
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
-            T = se - sb
             X = _mat(x, se, c, ldx)[sb:se].astype(np.float64)
-            xp = np.concatenate([np.repeat(X[:1], 5, 0), X, np.repeat(X[-1:], 5, 0)], 0)  # replicate pad 5/5
-            full = np.zeros((2 * (T + 10) + 10, c))
-            for m in range(T + 10):  # conv_transpose1d stride 2
-                full[2 * m:2 * m + 12] += xp[m][None, :] * f[:, None]
-            u = 2.0 * full[15:15 + 2 * T]
-            s = u + ib * np.sin(u * ea) ** 2
-            sp = np.concatenate([np.repeat(s[:1], 5, 0), s, np.repeat(s[-1:], 6, 0)], 0)
-            out = np.stack([(sp[2 * t:2 * t + 12] * f[:, None]).sum(0) for t in range(T)], 0)
-            _mat(y, se, c, ldy)[sb:se] = out.astype(np.float32)
+            _mat(y, se, c, ldy)[sb:se] = _snake_seq(X, _arr(alpha, c), _arr(beta, c), _arr(filt, 12)).astype(np.float32)
         return 0
 
     def tts_conv_post(self, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, stream):

@@ -153,6 +153,26 @@ def test_bf16_vocoder_within_stated_tolerance():
         assert err.mean() < 2e-2, (kind, float(err.mean()), float(err.max()))
 
 
+def test_unfused_snake_path_agrees_with_fused(vocoders):
+    g = _gold("L20_pred")
+    mel = torch.from_numpy(g["mel"]).to(DEV).contiguous()
+    voc = engine.VocoderEngine(fw.bigvgan_state_dict(), "bigvgan", DEV, fuse_snake=False)
+    wav, _ = voc.forward(mel, Ragged([mel.shape[0]], DEV))
+    assert np.abs(wav.cpu().numpy() - g["wav_bigvgan"]).max() < 5e-4
+
+
+def test_bf16_acoustic_within_stated_tolerance():
+    """configs[2] precision: bf16 MFMA GEMMs, fp32 activations/statistics.  Stated tolerance vs the fp32 reference golden:
+    mel mean-abs error < 0.05 (|mel| ~ 4, i.e. ~1 %); gold durations so the frame count is identical."""
+    g = _gold("L128_gold5")
+    ac = engine.AcousticEngine(fw.acoustic_state_dict(), DEV, bf16=True)
+    texts, embs, langs, zs = _inputs([g])
+    out = ac.forward(texts, embs, langs, z_noise=zs, durations=[torch.from_numpy(g["gold_durations"])])
+    err = np.abs(out["mel"][0].cpu().numpy() - g["mel"])
+    print("bf16 acoustic: mel mean abs err", float(err.mean()), "max", float(err.max()))
+    assert err.mean() < 0.05, float(err.mean())
+
+
 def test_native_library_is_the_one_loaded():
     from ims_toucan_prosody_variance_amd import capi
     import ctypes

@@ -92,6 +92,27 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute):
     close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
 
 
+@pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 257]), (64, 11, 5, [300, 40]), (256, 7, 3, [130, 1, 2]), (128, 3, 5, [64, 8])])
+@pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
+def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compute):
+    """TTS_PRE_SNAKE: the conv's input staging applies Activation1d(SnakeBeta) (AMP.py:53-56) - ragged edges included."""
+    w = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
+    b = rnd(c, seed=2, scale=0.1).numpy()
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        R = rag.total_rows
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, bf16=True)
+        x = to(rnd(R, c, seed=3))
+        y = to(torch.zeros(R, c))
+        res = to(rnd(R, c, seed=5))
+        sn = (to(rnd(c, seed=6, scale=0.3)), to(rnd(c, seed=7, scale=0.3)), to(torch.from_numpy(packing.kaiser_sinc_filter12())))
+        return ops.conv(cw, x, y, rag, pre=capi.PRE_SNAKE, snake=sn, res=res, compute=compute)
+
+    g, cc = both(gpu, cpu, run)
+    close(g, cc, 3e-5 if compute == capi.COMPUTE_F32 else 2e-2)
+
+
 def test_conv1d_rows_outside_utterances_are_untouched(gpu):
     rag = Ragged([5, 3], gpu.device, align=2)  # rows 5 and 9 are alignment padding
     cw = packing.pack_conv(rnd(32, 32, 3).numpy(), None, gpu.device)
