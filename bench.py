@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--vocoder", default="bigvgan", choices=["bigvgan", "hifigan"])
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,7 +99,7 @@ def main():
     log("building engines (fixture weights)")
     ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, bf16=bf16)
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
-    voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, bf16=bf16)
+    voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, bf16=bf16, fuse_snake=args.fuse_snake)
 
     B, L, T = args.batch, args.phones, args.phones * args.frames_per_phone
     log(f"synthetic inputs: {B} x {L} phonemes -> {T} frames per utterance")

@@ -153,10 +153,10 @@ def test_bf16_vocoder_within_stated_tolerance():
         assert err.mean() < 2e-2, (kind, float(err.mean()), float(err.max()))
 
 
-def test_unfused_snake_path_agrees_with_fused(vocoders):
+def test_fused_snake_path_agrees_with_unfused(vocoders):
     g = _gold("L20_pred")
     mel = torch.from_numpy(g["mel"]).to(DEV).contiguous()
-    voc = engine.VocoderEngine(fw.bigvgan_state_dict(), "bigvgan", DEV, fuse_snake=False)
+    voc = engine.VocoderEngine(fw.bigvgan_state_dict(), "bigvgan", DEV, fuse_snake=True)
     wav, _ = voc.forward(mel, Ragged([mel.shape[0]], DEV))
     assert np.abs(wav.cpu().numpy() - g["wav_bigvgan"]).max() < 5e-4
 
