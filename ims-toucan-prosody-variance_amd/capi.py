@@ -43,6 +43,22 @@ class TtsConvDesc(C.Structure):
     ]
 
 
+class TtsResblockDesc(C.Structure):
+    _fields_ = [
+        ("x", _p), ("ldx", _i),
+        ("y", _p), ("ldy", _i),
+        ("c", _i), ("taps", _i), ("dil", _i),
+        ("w1", _p), ("b1", _p),
+        ("w2", _p), ("b2", _p),
+        ("act", _i), ("slope", _f),
+        ("alpha1", _p), ("beta1", _p), ("alpha2", _p), ("beta2", _p), ("filt", _p),
+        ("alpha", _f), ("res_scale", _f), ("accumulate", _i),
+        ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
+    ]
+
+
+RESBLOCK_TILE_ROWS = 224
+
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
 PROTOTYPES = {
     "tts_last_error": (C.c_char_p, []),
@@ -50,6 +66,7 @@ PROTOTYPES = {
     "tts_conv1d_tile_rows": (C.c_int, [_i, _i]),
     "tts_conv1d_n_tile": (C.c_int, [_i, _i]),
     "tts_conv1d": (C.c_int, [C.POINTER(TtsConvDesc), _p]),
+    "tts_resblock_step": (C.c_int, [C.POINTER(TtsResblockDesc), _p]),
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     "tts_l2_normalize": (C.c_int, [_p, _p, _i, _i, _p]),

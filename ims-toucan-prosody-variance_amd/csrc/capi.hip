@@ -37,6 +37,7 @@ int glow_invconv_actnorm(float*, int, int, int, const float*, const float*, cons
 int snake_aa(const float*, int, float*, int, const float*, const float*, const float*, int, const TtsTile*, int, int, hipStream_t);
 int conv_post(const float*, int, int, const float*, float, int, float, float*, const TtsTile*, int, int, hipStream_t);
 int gather_rows(const float*, int, const int*, float*, int, int, int, hipStream_t);
+int resblock_step(const TtsResblockDesc& d, hipStream_t st);
 
 }  // namespace tts
 
@@ -56,6 +57,14 @@ int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream) {
     return TTS_E_ARG;
   }
   return tts::conv1d_dispatch(*d, ST(stream));
+}
+
+int tts_resblock_step(const TtsResblockDesc* d, tts_stream_t stream) {
+  if (!d) {
+    tts::set_error("tts_resblock_step: null descriptor");
+    return TTS_E_ARG;
+  }
+  return tts::resblock_step(*d, ST(stream));
 }
 
 int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta, int32_t rows, int32_t c,

@@ -1,0 +1,268 @@
+// Fused vocoder residual step:   y = alpha * conv2(act2(conv1(act1(x)))) + res_scale * x   (+ y)
+//
+// One launch replaces the four ops of one dilation step of a BigVGAN AMP block (AMP.py:53-58: a1, c1, a2, c2, + x)
+// or of a HiFiGAN residual block (ResidualBlock.py:93-97: LeakyReLU, conv, LeakyReLU, conv, + x).  The
+// intermediate tensors (act1(x), conv1 output, act2 of it) exist only in LDS, so HBM sees one read of x (plus
+// its halo) and one write of y instead of nine full-tensor passes.
+//
+// Decomposition (512 threads = 8 wavefronts, one utterance per workgroup via the tile table):
+//   * output tile: BM = 224 rows; conv1 is evaluated on M1 = 256 rows (BM + 16 each side: conv2's halo <= 5 and the
+//     anti-alias filter's halo 6), wave w owns rows 32w..32w+31 and all C columns (C/32 accumulators of 32x32).
+//   * act1(x) window (M1 + 2*h1 rows, h1 = (k-1)/2*dil) is staged per 64-channel slab as bf16; the anti-aliased snake
+//     is computed in registers while staging (snake.h), LeakyReLU element-wise.
+//   * conv1 accumulators (+bias) go to LDS as bf16 (t1, M1 x C); the second activation runs in place on t1
+//     (snake: every item first computes its 8 outputs into registers, barrier, then overwrites).
+//   * conv2 (dilation 1) reads its A operand straight from t1; waves 0..6 own the 224 output rows.
+//   * weight slabs of both convs stream through one double-buffered LDS ring with register prefetch.
+//   * epilogue: + bias2, alpha, + res_scale * x (re-read from global, L2-resident), optional accumulate, fp32 store.
+// Rows outside the utterance are zero after each activation (the reference zero-pads every conv per utterance).
+// bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
+#include "common.h"
+#include "snake.h"
+
+namespace tts {
+
+__device__ __forceinline__ unsigned short rb_f2bf(float f) {
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float rb_bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned int)u << 16); }
+
+constexpr int RB_BM = 224, RB_M1 = 256, RB_LEAD = 16, RB_THREADS = 512;
+
+// waves per SIMD the register allocation must leave room for: 3 / 2 / 1 workgroups per CU (C = 32 / 64 / 128; LDS allows no more)
+template <int C>
+__global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void resblock_step_kernel(const TtsResblockDesc d) {
+  constexpr int KC = C < 64 ? C : 64;     // channels per slab
+  constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
+  constexpr int TP = C + 8;               // t1 pitch
+  constexpr int TN = C / 32;              // 32-column accumulators per wave
+  constexpr int NCH = C / KC;             // slabs per conv
+  constexpr int SLAB = KC * C;            // bf16 elements of one weight slab [KC/8][C][8]
+  constexpr int UNITS = SLAB / 8;         // 16-byte units
+  constexpr int UPT = (UNITS + RB_THREADS - 1) / RB_THREADS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+  const TtsTile tile = d.tiles[blockIdx.x];
+  const int h1 = (d.taps - 1) / 2 * d.dil, h2 = (d.taps - 1) / 2;
+  const int win_rows = RB_M1 + 2 * h1;
+  // xa (act1(x) window) is dead once conv1 has finished, so t1 (conv1 output) overlays it
+  const size_t xa_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7, t1_elems = (size_t)RB_M1 * TP;
+  unsigned short* xa = reinterpret_cast<unsigned short*>(lds_raw);          // [win_rows][XP]
+  unsigned short* t1 = xa;                                                  // [M1][TP]
+  unsigned short* ws = xa + (xa_elems > t1_elems ? xa_elems : t1_elems);    // [2][SLAB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lk = lane >> 5;
+  const int T = tile.seq_end - tile.seq_begin;
+  const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
+  const bool snake = d.act == TTS_PRE_SNAKE;
+  const int steps1 = NCH * d.taps, total_steps = 2 * steps1;
+
+  uint4 wreg[UPT];
+  auto load_slab = [&](int step) {
+    const bool second = step >= steps1;
+    const int s = second ? step - steps1 : step;
+    const int chunk = s / d.taps, tap = s % d.taps;
+    const unsigned short* W = reinterpret_cast<const unsigned short*>(second ? d.w2 : d.w1);
+    const unsigned short* src = W + ((size_t)tap * (C / 8) + chunk * (KC / 8)) * C * 8;  // [tap][C/8][C][8]
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const int u = tid + q * RB_THREADS;
+      if (u < UNITS) wreg[q] = *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < UPT; ++q) {
+      const int u = tid + q * RB_THREADS;
+      if (u < UNITS) *reinterpret_cast<uint4*>(ws + (size_t)buf * SLAB + (size_t)u * 8) = wreg[q];
+    }
+  };
+  load_slab(0);
+  store_slab(0);
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+  float f[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) f[k] = snake ? d.filt[k] : 0.0f;
+
+  // ------------------------------------------------------------------ conv1 over act1(x)
+  int step = 0;
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = ch * KC;
+    if (ch > 0) __syncthreads();
+    // window row j <-> local frame l0 - LEAD - h1 + j
+    const int wbase = l0 - RB_LEAD - h1;
+    if (snake) {
+      const int items = ((win_rows + 7) >> 3) * KC;
+      for (int it = tid; it < items; it += RB_THREADS) {
+        const int chl = it % KC, wr0 = (it / KC) * 8;
+        const int cg = c0 + chl;
+        const int t0 = wbase + wr0;
+        float o[8];
+        const bool live = t0 + 7 >= 0 && t0 < T;
+        if (live) snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, expf(d.alpha1[cg]), 1.0f / (expf(d.beta1[cg]) + 1e-9f), o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = rb_f2bf((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
+      }
+    } else {
+      constexpr int Q4 = KC / 4;
+      for (int e = tid; e < win_rows * Q4; e += RB_THREADS) {
+        const int wr = e / Q4, c4 = (e % Q4) * 4;
+        const int t = wbase + wr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) v = *reinterpret_cast<const float4*>(d.x + (size_t)(tile.seq_begin + t) * d.ldx + c0 + c4);
+        ushort4 o;
+        o.x = rb_f2bf(v.x > 0.f ? v.x : v.x * d.slope);
+        o.y = rb_f2bf(v.y > 0.f ? v.y : v.y * d.slope);
+        o.z = rb_f2bf(v.z > 0.f ? v.z : v.z * d.slope);
+        o.w = rb_f2bf(v.w > 0.f ? v.w : v.w * d.slope);
+        *reinterpret_cast<ushort4*>(xa + wr * XP + c4) = o;
+      }
+    }
+    for (int tap = 0; tap < d.taps; ++tap, ++step) {
+      __syncthreads();
+      load_slab(step + 1);  // step + 1 < total_steps always holds here (conv2 follows)
+      const unsigned short* wb = ws + (size_t)(step & 1) * SLAB;
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + (wave * 32 + lrow + tap * d.dil) * XP + ks * 16 + lk * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+        }
+      }
+      store_slab((step + 1) & 1);
+    }
+  }
+
+  // ------------------------------------------------------------------ t1 = conv1 + bias (LeakyReLU applied here), bf16 in LDS
+  // t1 row i <-> local frame l0 - LEAD + i
+  __syncthreads();  // every wave is done reading xa (t1 overlays it)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = j * 32 + lrow;
+    const float b1 = d.b1[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const int t = l0 - RB_LEAD + i;
+      float v = acc[j][r] + b1;
+      if (!snake) v = v > 0.f ? v : v * d.slope;
+      if (t < 0 || t >= T) v = 0.0f;  // act2 output outside the utterance is conv2's zero padding
+      t1[i * TP + n] = rb_f2bf(v);
+      acc[j][r] = 0.0f;
+    }
+  }
+  __syncthreads();
+  if (snake) {
+    // second anti-aliased snake, in place on t1: compute all outputs of this thread into registers, then overwrite
+    constexpr int ITEMS = (RB_M1 / 8) * C / RB_THREADS;  // C/16
+    float o[ITEMS][8];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int it = tid + q * RB_THREADS;
+      const int chn = it % C, i0 = (it / C) * 8;
+      const int t0 = l0 - RB_LEAD + i0;
+      const bool live = t0 + 7 >= 0 && t0 < T;
+      if (live) {
+        const int base = l0 - RB_LEAD;  // local frame of t1 row 0
+        snake_rows_fn<8>([&](int q2) {
+          int i = q2 - base;
+          i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);  // only reached by rows whose outputs are not consumed
+          return rb_bf2f(t1[i * TP + chn]);
+        }, T, t0, f, expf(d.alpha2[chn]), 1.0f / (expf(d.beta2[chn]) + 1e-9f), o[q]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (!(live && t0 + i >= 0 && t0 + i < T)) o[q][i] = 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int it = tid + q * RB_THREADS;
+      const int chn = it % C, i0 = (it / C) * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t1[(i0 + i) * TP + chn] = rb_f2bf(o[q][i]);
+    }
+  }
+
+  // ------------------------------------------------------------------ conv2 (dilation 1) over t1; output row o <-> t1 row LEAD + o
+  for (int ch = 0; ch < NCH; ++ch) {
+    for (int tap = 0; tap < d.taps; ++tap, ++step) {
+      __syncthreads();
+      const bool more = step + 1 < total_steps;
+      if (more) load_slab(step + 1);
+      if (wave < RB_BM / 32) {
+        const unsigned short* wb = ws + (size_t)(step & 1) * SLAB;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + ks * 16 + lk * 8);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+          }
+        }
+      }
+      if (more) store_slab((step + 1) & 1);
+    }
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  if (wave < RB_BM / 32) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = j * 32 + lrow;
+      const float b2 = d.b2[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tile.row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= tile.seq_end) continue;
+        float v = d.alpha * (acc[j][r] + b2) + d.res_scale * d.x[(size_t)row * d.ldx + n];
+        float* yp = d.y + (size_t)row * d.ldy + n;
+        if (d.accumulate) v += *yp;
+        *yp = v;
+      }
+    }
+  }
+}
+
+template <int C>
+static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
+  constexpr int KC = C < 64 ? C : 64;
+  const int h1 = (d.taps - 1) / 2 * d.dil;
+  const size_t xa = (((size_t)(RB_M1 + 2 * h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
+  const size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * KC * C) * 2;
+  TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
+  auto k = resblock_step_kernel<C>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(d.n_tiles), dim3(RB_THREADS), lds, st, d);
+  return launch_status("resblock_step");
+}
+
+int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
+  TTS_CHECK_ARG(d.x && d.y && d.w1 && d.w2 && d.b1 && d.b2 && d.tiles, "resblock_step: null pointer");
+  TTS_CHECK_ARG(d.c == 32 || d.c == 64 || d.c == 128, "resblock_step: C=%d unsupported (32, 64, 128)", d.c);
+  TTS_CHECK_ARG(d.taps >= 1 && d.taps <= 11 && (d.taps & 1) && d.dil >= 1, "resblock_step: taps %d / dil %d unsupported", d.taps, d.dil);
+  TTS_CHECK_ARG((d.taps - 1) / 2 + 6 <= RB_LEAD, "resblock_step: conv2 halo too large");
+  TTS_CHECK_ARG(d.tile_rows == RB_BM, "resblock_step: tile table must use %d rows, got %d", RB_BM, d.tile_rows);
+  TTS_CHECK_ARG(d.act == TTS_PRE_LRELU || d.act == TTS_PRE_SNAKE, "resblock_step: act must be LRELU or SNAKE");
+  TTS_CHECK_ARG(d.act != TTS_PRE_SNAKE || (d.alpha1 && d.beta1 && d.alpha2 && d.beta2 && d.filt), "resblock_step: snake parameters missing");
+  TTS_CHECK_ARG((d.ldx & 3) == 0 && ((uintptr_t)d.x & 15) == 0, "resblock_step: x must be 16-byte aligned rows");
+  if (d.n_tiles == 0) return TTS_OK;
+  switch (d.c) {
+    case 32: return launch_rb<32>(d, st);
+    case 64: return launch_rb<64>(d, st);
+    default: return launch_rb<128>(d, st);
+  }
+}
+
+}  // namespace tts

@@ -20,19 +20,18 @@ __device__ __forceinline__ float sin_sq(float a) {
   return sn * sn;
 }
 
-// out[i] = snake_aa(x)[t0 + i] for i < ROWS; t0 is the local frame index inside an utterance of T frames whose first
-// packed row is seq_begin.  t0 may be negative / rows may lie beyond T: those outputs are meaningless (callers mask
-// them), but every output with 0 <= t0+i < T is exact provided the group overlaps [0, T).
-template <int ROWS>
-__device__ __forceinline__ void snake_rows(const float* __restrict__ x, int ldx, int ch, int seq_begin, int T, int t0,
-                                           const float (&f)[12], float ea, float inv_b, float (&out)[ROWS]) {
+// out[i] = snake_aa(x)[t0 + i] for i < ROWS; t0 is the local frame index inside an utterance of T frames; load(q) returns
+// frame q of the utterance (0 <= q < T, already clamped).  t0 may be negative / rows may lie beyond T: those outputs are
+// meaningless (callers mask them), but every output with 0 <= t0+i < T is exact provided the group overlaps [0, T).
+template <int ROWS, class LoadFn>
+__device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const float (&f)[12], float ea, float inv_b, float (&out)[ROWS]) {
   constexpr int NX = ROWS + 12, NS = 2 * ROWS + 10;
   float xin[NX];  // x[t0-6 .. t0+ROWS+5], replicate padded inside the utterance
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     int q = t0 - 6 + i;
     q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
-    xin[i] = x[(size_t)(seq_begin + q) * ldx + ch];
+    xin[i] = load(q);
   }
   float s[NS];  // s[m] <-> n = 2*t0 - 5 + m
 #pragma unroll
@@ -72,6 +71,13 @@ __device__ __forceinline__ void snake_rows(const float* __restrict__ x, int ldx,
     for (int k = 0; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
     out[i] = a;
   }
+}
+
+// The same on a packed fp32 tensor in global memory: channel ch of the utterance starting at packed row seq_begin.
+template <int ROWS>
+__device__ __forceinline__ void snake_rows(const float* __restrict__ x, int ldx, int ch, int seq_begin, int T, int t0,
+                                           const float (&f)[12], float ea, float inv_b, float (&out)[ROWS]) {
+  snake_rows_fn<ROWS>([&](int q) { return x[(size_t)(seq_begin + q) * ldx + ch]; }, T, t0, f, ea, inv_b, out);
 }
 
 }  // namespace tts

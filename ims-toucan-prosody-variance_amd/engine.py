@@ -86,6 +86,33 @@ class Ops:
             capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
         return y
 
+    def resblock_step(self, c1, c2, x, y, rag, act, slope=0.1, snake1=None, snake2=None, filt=None, alpha=1.0, res_scale=1.0,
+                      accumulate=False):
+        """Fused residual step (tts_resblock_step): y = alpha*conv2(act(conv1(act(x)))) + res_scale*x (+ y)."""
+        tiles, n_tiles = rag.tiles(capi.RESBLOCK_TILE_ROWS)
+        d = capi.TtsResblockDesc()
+        d.x, d.ldx, d.y, d.ldy = x.data_ptr(), _ld(x), y.data_ptr(), _ld(y)
+        d.c, d.taps, d.dil = c1.cin, c1.taps, c1.dil
+        d.w1, d.b1, d.w2, d.b2 = c1.w_bf16.data_ptr(), c1.bias.data_ptr(), c2.w_bf16.data_ptr(), c2.bias.data_ptr()
+        d.act, d.slope = act, slope
+        if snake1 is not None:
+            d.alpha1, d.beta1 = snake1[0].data_ptr(), snake1[1].data_ptr()
+            d.alpha2, d.beta2 = snake2[0].data_ptr(), snake2[1].data_ptr()
+            d.filt = filt.data_ptr()
+        d.alpha, d.res_scale, d.accumulate = alpha, res_scale, 1 if accumulate else 0
+        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, capi.RESBLOCK_TILE_ROWS
+        tm = self.timer
+        if tm is not None and tm.wants_name("resblock_step<%d>" % c1.cin):
+            ev0, ev1 = tm.events()
+            ev0.record()
+            capi.check(self.lib.tts_resblock_step(C.byref(d), self.stream()), "tts_resblock_step")
+            ev1.record()
+            rows = sum(rag.lengths)
+            tm.add_named("resblock_step<%d>" % c1.cin, 2.0 * rows * c1.cin * c1.cin * c1.taps * 2, ev0, ev1)
+        else:
+            capi.check(self.lib.tts_resblock_step(C.byref(d), self.stream()), "tts_resblock_step")
+        return y
+
     def layernorm(self, x, y, gamma, beta, rows, c, eps=1e-12):
         capi.check(self.lib.tts_layernorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), gamma.data_ptr(), beta.data_ptr(), rows, c, eps,
                                           self.stream()), "tts_layernorm")
@@ -490,13 +517,15 @@ class VocoderEngine:
     KS = (3, 7, 11)
     DIL = (1, 3, 5)
 
-    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False):
+    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False, fuse_step=None):
         assert kind in ("bigvgan", "hifigan")
         self.kind = kind
         # BigVGAN: run the anti-aliased snake inside the convs' input staging (TTS_PRE_SNAKE, no extra HBM round trip) or as
         # its own kernel.  Measured on MI355X (batch 32, bf16): 122.5 ms/step fused vs 119.0 ms/step unfused - the fused
         # variant needs 111-131 VGPRs and loses occupancy, so the stand-alone kernel is the default for now.
         self.fuse_snake = fuse_snake
+        # bf16 only: one fused kernel per residual dilation step (tts_resblock_step) for the stages with C <= 128
+        self.fuse_step = bf16 if fuse_step is None else (fuse_step and bf16)
         self.ops = Ops(device)
         self.device = self.ops.device
         self.compute = COMPUTE_BF16 if bf16 else COMPUTE_F32
@@ -555,6 +584,14 @@ class VocoderEngine:
                 for dd in range(3):
                     c1, c2 = self.blocks[i][j][dd]
                     last = dd == 2
+                    if self.fuse_step and ch <= 128:
+                        # one launch per dilation step: act, conv(dil), act, conv(1), + x (and the stage mean on the last step)
+                        sn1, sn2 = self.snakes[i][j][dd] if big else (None, None)
+                        dst = stage_out if last else bufs[dd % 2]
+                        ops.resblock_step(c1, c2, cur, dst, rag, PRE_SNAKE if big else PRE_LRELU, 0.1, sn1, sn2, self.filt if big else None,
+                                          alpha=1.0 / 3.0 if last else 1.0, res_scale=1.0 / 3.0 if last else 1.0, accumulate=last and j > 0)
+                        cur = dst
+                        continue
                     if big:  # AMP.py:51-60: a1 -> c1 -> a2 -> c2 -> + x; both activations run inside the convs' input staging
                         (a1, b1), (a2, b2) = self.snakes[i][j][dd]
                         if self.fuse_snake:

@@ -24,6 +24,12 @@ class ConvTimer:
     def wants(self, cw, compute):
         return self.enabled and (self.select is None or kernel_class(cw, compute) in self.select)
 
+    def wants_name(self, name):
+        return self.enabled and (self.select is None or name in self.select)
+
+    def add_named(self, name, flops, ev0, ev1):
+        self.records.append((name, flops, ev0, ev1))
+
     def events(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 

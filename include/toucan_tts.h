@@ -90,6 +90,30 @@ int tts_conv1d_tile_rows(int32_t cout, int32_t mode);
 int tts_conv1d_n_tile(int32_t cout, int32_t mode);
 int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream);
 
+/*
+ * Fused vocoder residual step (bf16 MFMA, fp32 accumulate, fp32 tensors in HBM):
+ *   y = alpha * conv2(act(conv1(act(x)) + b1)) + b2) + res_scale * x   (+ y if accumulate)
+ * conv1: `taps` taps, dilation `dil`; conv2: `taps` taps, dilation 1; both C -> C, 'same' zero padding per utterance.
+ * act = TTS_PRE_LRELU (slope) or TTS_PRE_SNAKE (anti-aliased SnakeBeta with (alpha1,beta1) / (alpha2,beta2), filter [12]).
+ * Replaces one dilation step of BigVGAN/AMP.py:53-58 (a1, c1, a2, c2, + x) or Layers/ResidualBlock.py:93-97; with
+ * alpha = res_scale = 1/3 and accumulate it also forms the stage mean of InferenceBigVGAN.py:82-88.
+ * Weights: bf16 [taps][C/8][C][8] as produced for tts_conv1d(compute = 1).  The tile table must use 224 rows per tile.
+ */
+typedef struct {
+  const float* x; int32_t ldx;
+  float* y;       int32_t ldy;
+  int32_t c, taps, dil;
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  int32_t act; float slope;
+  const float* alpha1; const float* beta1; const float* alpha2; const float* beta2; const float* filt;
+  float alpha, res_scale; int32_t accumulate;
+  const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows;
+} TtsResblockDesc;
+
+#define TTS_RESBLOCK_TILE_ROWS 224
+int tts_resblock_step(const TtsResblockDesc* d, tts_stream_t stream);
+
 /* y[r,:] = LayerNorm(x[r,:]) * g + b over `c` channels, eps as given. Layers/LayerNorm.py:24-36 (eps 1e-12). */
 int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta,
                   int32_t rows, int32_t c, float eps, tts_stream_t stream);

@@ -158,6 +158,50 @@ class Emulator:
             y[sb:se] = v
         return 0
 
+    def tts_resblock_step(self, dref, stream):
+        """bf16 rounding points as in csrc/resblock.hip: act1(x) -> bf16; conv1 (+b1) -> bf16 (LeakyReLU before the
+        rounding, snake after it) -> act2 -> bf16; conv2; fp32 epilogue."""
+        self._count("resblock_step")
+        d = dref._obj
+        C_, k = d.c, d.taps
+
+        def wload(ptr):
+            raw = _arr(ptr, k * C_ * C_, np.uint16).reshape(k, C_ // 8, C_, 8)
+            return (raw.astype(np.uint32) << 16).view(np.float32).transpose(0, 1, 3, 2).reshape(k, C_, C_).astype(np.float64)
+
+        w1, w2 = wload(d.w1), wload(d.w2)
+        b1, b2 = _arr(d.b1, C_).astype(np.float64), _arr(d.b2, C_).astype(np.float64)
+        snake = d.act == capi.PRE_SNAKE
+        filt = _arr(d.filt, 12) if snake else None
+
+        def act(v, al, be):
+            if snake:
+                return _snake_seq(v, _arr(al, C_), _arr(be, C_), filt)
+            return np.where(v > 0, v, v * np.float64(np.float32(d.slope)))
+
+        def conv(v, w, dil):
+            n = v.shape[0]
+            h = (k - 1) // 2 * dil
+            vp = np.zeros((n + 2 * h, C_))
+            vp[h:h + n] = v
+            return sum(vp[j * dil:j * dil + n] @ w[j] for j in range(k))
+
+        for sb, se, sid in _seqs_from_tiles(_tiles(d.tiles, d.n_tiles)):
+            x = _mat(d.x, se, C_, d.ldx)[sb:se].astype(np.float64)
+            a1 = _bf16_round(act(x, d.alpha1, d.beta1).astype(np.float32)).astype(np.float64)
+            t = conv(a1, w1, d.dil) + b1
+            if snake:
+                t = _bf16_round(t.astype(np.float32)).astype(np.float64)
+                a2 = _bf16_round(act(t, d.alpha2, d.beta2).astype(np.float32)).astype(np.float64)
+            else:
+                a2 = _bf16_round(act(t, None, None).astype(np.float32)).astype(np.float64)
+            v = np.float32(d.alpha) * (conv(a2, w2, 1) + b2).astype(np.float32) + np.float32(d.res_scale) * x.astype(np.float32)
+            y = _mat(d.y, se, C_, d.ldy)
+            if d.accumulate:
+                v = v + y[sb:se]
+            y[sb:se] = v.astype(np.float32)
+        return 0
+
     def tts_layernorm(self, x, ldx, y, ldy, gamma, beta, rows, c, eps, stream):
         self._count("layernorm")
         X = _mat(x, rows, c, ldx).astype(np.float64)

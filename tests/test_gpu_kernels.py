@@ -113,6 +113,31 @@ def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compu
     close(g, cc, 3e-5 if compute == capi.COMPUTE_F32 else 2e-2)
 
 
+@pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 225]), (32, 11, 5, [700, 30]), (64, 7, 3, [224, 449, 1]), (64, 11, 5, [300]),
+                                             (128, 3, 1, [500, 17]), (128, 11, 5, [260, 100]), (128, 7, 1, [2, 223])])
+@pytest.mark.parametrize("act", [capi.PRE_LRELU, capi.PRE_SNAKE])
+def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act):
+    """tts_resblock_step against the emulator (same bf16 rounding points) on ragged batches incl. tile-boundary lengths."""
+    w1 = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
+    w2 = rnd(c, c, k, seed=2, scale=1.0 / np.sqrt(c * k)).numpy()
+    b1, b2 = rnd(c, seed=3, scale=0.1).numpy(), rnd(c, seed=4, scale=0.1).numpy()
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        R = rag.total_rows
+        c1 = packing.pack_conv(w1, b1, ops.device, dil=dil, bf16=True)
+        c2 = packing.pack_conv(w2, b2, ops.device, dil=1, bf16=True)
+        x = to(rnd(R, c, seed=5))
+        y = to(rnd(R, c, seed=6))
+        sn1 = (to(rnd(c, seed=7, scale=0.3)), to(rnd(c, seed=8, scale=0.3)))
+        sn2 = (to(rnd(c, seed=9, scale=0.3)), to(rnd(c, seed=10, scale=0.3)))
+        filt = to(torch.from_numpy(packing.kaiser_sinc_filter12()))
+        return ops.resblock_step(c1, c2, x, y, rag, act, 0.1, sn1, sn2, filt, alpha=1.0 / 3.0, res_scale=1.0 / 3.0, accumulate=True)
+
+    g, cc = both(gpu, cpu, run)
+    close(g, cc, 1e-2)
+
+
 def test_conv1d_rows_outside_utterances_are_untouched(gpu):
     rag = Ragged([5, 3], gpu.device, align=2)  # rows 5 and 9 are alignment padding
     cw = packing.pack_conv(rnd(32, 32, 3).numpy(), None, gpu.device)

@@ -104,3 +104,17 @@ def test_vocoder_engine_matches_reference_golden(emu, kind):
     assert wav.numel() == 384 * mel.shape[0]
     np.testing.assert_allclose(taps["voc_stage0"].numpy(), g[f"tap_{kind}_stage0"].T, atol=1e-4)
     np.testing.assert_allclose(wav.numpy(), g["wav_" + kind], atol=2e-4)
+
+
+@pytest.mark.parametrize("kind", ["hifigan", "bigvgan"])
+def test_bf16_vocoder_engine_with_fused_residual_steps(emu, kind):
+    """bf16 configuration (fused tts_resblock_step for C <= 128) stays within the stated bf16 tolerance of the fp32 golden."""
+    g = _gold("L7_pred")
+    sd = fw.hifigan_state_dict() if kind == "hifigan" else fw.bigvgan_state_dict()
+    voc = engine.VocoderEngine(sd, kind, "cpu", bf16=True)
+    from ims_toucan_prosody_variance_amd.ragged import Ragged
+    mel = torch.from_numpy(g["mel"]).contiguous()
+    wav, rag = voc.forward(mel, Ragged([mel.shape[0]], "cpu"))
+    assert emu.calls.get("resblock_step", 0) == 27  # 3 stages x 3 blocks x 3 dilations
+    err = np.abs(wav.numpy() - g["wav_" + kind])
+    assert err.mean() < 2e-2, float(err.mean())
