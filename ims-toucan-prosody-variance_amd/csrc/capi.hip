@@ -28,6 +28,8 @@ int groupnorm(const float*, int, float*, int, const float*, const float*, int, i
 int axpby(const float*, int, float, const float*, int, float, float*, int, int, int, hipStream_t);
 int relpos_attention(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
                      int, hipStream_t);
+int relpos_attention_mfma(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
+                          int, hipStream_t);
 int dwconv_swish(const float*, int, float*, int, const float*, const float*, int, int, const TtsTile*, int, int, hipStream_t);
 int duration_from_log(const float*, int*, int, hipStream_t);
 int prosody_control(const float*, int, float*, float*, int*, const int*, const int*, int, float, float, float, float, hipStream_t);
@@ -90,6 +92,9 @@ int tts_groupnorm(const float* x, int32_t ldx, float* y, int32_t ldy, const floa
 int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u, const float* bias_v,
                          float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk, const TtsTile* tiles, int32_t n_tiles,
                          int32_t tile_rows, tts_stream_t stream) {
+  // 128-row tiles: matrix-core kernel (attention_mfma.hip); 64-row tiles: the VALU kernel (attention.hip)
+  if (tile_rows == 128)
+    return tts::relpos_attention_mfma(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
   return tts::relpos_attention(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
 }
 

@@ -114,15 +114,20 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         size_t goff;
         bool ok;
         if constexpr (BF16) {
-          const int kb = u / BN, n = u % BN;
+          int kb = u / BN;
+          const int n = u % BN;
           ok = kb * 8 < kchunk;
+          kb = ok ? kb : 0;  // always a valid address: the load is unconditional (no branch, no early wait), the value is masked
           goff = (((size_t)tap * (d.cin_pad / 8) + c0 / 8 + kb) * d.wn + n0 + h * d.half_pad + n) * 8;
         } else {
-          const int k = u / (BN / 4), c4 = (u % (BN / 4)) * 4;
+          int k = u / (BN / 4);
+          const int c4 = (u % (BN / 4)) * 4;
           ok = k < kchunk;
+          k = ok ? k : 0;
           goff = ((size_t)tap * d.cin_pad + c0 + k) * d.wn + n0 + h * d.half_pad + c4;
         }
-        wreg[h][q] = ok ? *reinterpret_cast<const uint4*>(W + goff) : make_uint4(0, 0, 0, 0);
+        const uint4 v = *reinterpret_cast<const uint4*>(W + goff);
+        wreg[h][q] = ok ? v : make_uint4(0, 0, 0, 0);
       }
   };
   auto store_slab = [&](int buf) {
@@ -167,18 +172,36 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           if (wr0 + i < win_rows) xs[(wr0 + i) * XP + chl] = Elem<BF16>::cvt((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
       }
     } else if (vec_ok) {
+      // PER independent 16-byte loads per thread are issued back to back (clamped addresses, no branches) before any of
+      // them is consumed, so one trip pays the memory latency once instead of PER times
+      constexpr int PER = 4;
       const int q4 = kchunk >> 2;  // float4 groups per row
-      for (int e = tid; e < win_rows * q4; e += 256) {
-        const int wr = e / q4, c4 = (e % q4) * 4;
-        const int gr = row_first + wr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c4) < d.cin)
-          v = *reinterpret_cast<const float4*>(d.x + (size_t)gr * d.ldx + c0 + c4);
-        ET* dst = xs + wr * XP + c4;
-        dst[0] = Elem<BF16>::cvt(pre_activation(v.x, d.pre_act, d.pre_slope));
-        dst[1] = Elem<BF16>::cvt(pre_activation(v.y, d.pre_act, d.pre_slope));
-        dst[2] = Elem<BF16>::cvt(pre_activation(v.z, d.pre_act, d.pre_slope));
-        dst[3] = Elem<BF16>::cvt(pre_activation(v.w, d.pre_act, d.pre_slope));
+      const int total = win_rows * q4;
+      for (int base = tid; base < total; base += 256 * PER) {
+        float4 v[PER];
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          int e = base + p * 256;
+          e = e < total ? e : total - 1;  // tail duplicates the last element (same value, benign)
+          const int wr = e / q4, c4 = (e % q4) * 4;
+          const int gr = row_first + wr;
+          const bool ok = gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c4) < d.cin;
+          const int grc = gr < tile.seq_begin ? tile.seq_begin : (gr >= tile.seq_end ? tile.seq_end - 1 : gr);
+          const int cc = (c0 + c4) < d.cin ? (c0 + c4) : d.cin - 4;
+          v[p] = *reinterpret_cast<const float4*>(d.x + (size_t)grc * d.ldx + cc);
+          if (!ok) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          int e = base + p * 256;
+          e = e < total ? e : total - 1;
+          const int wr = e / q4, c4 = (e % q4) * 4;
+          ET* dst = xs + wr * XP + c4;
+          dst[0] = Elem<BF16>::cvt(pre_activation(v[p].x, d.pre_act, d.pre_slope));
+          dst[1] = Elem<BF16>::cvt(pre_activation(v[p].y, d.pre_act, d.pre_slope));
+          dst[2] = Elem<BF16>::cvt(pre_activation(v[p].z, d.pre_act, d.pre_slope));
+          dst[3] = Elem<BF16>::cvt(pre_activation(v[p].w, d.pre_act, d.pre_slope));
+        }
       }
     } else {
       for (int e = tid; e < win_rows * kchunk; e += 256) {

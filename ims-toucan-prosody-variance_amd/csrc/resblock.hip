@@ -67,8 +67,9 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
     const unsigned short* src = W + ((size_t)tap * (C / 8) + chunk * (KC / 8)) * C * 8;  // [tap][C/8][C][8]
 #pragma unroll
     for (int q = 0; q < UPT; ++q) {
-      const int u = tid + q * RB_THREADS;
-      if (u < UNITS) wreg[q] = *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
+      int u = tid + q * RB_THREADS;
+      u = u < UNITS ? u : UNITS - 1;  // unconditional load (idle threads re-read the last unit): no branch, no early wait
+      wreg[q] = *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
     }
   };
   auto store_slab = [&](int buf) {
@@ -112,18 +113,33 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
           if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = rb_f2bf((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
       }
     } else {
-      constexpr int Q4 = KC / 4;
-      for (int e = tid; e < win_rows * Q4; e += RB_THREADS) {
-        const int wr = e / Q4, c4 = (e % Q4) * 4;
-        const int t = wbase + wr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < T) v = *reinterpret_cast<const float4*>(d.x + (size_t)(tile.seq_begin + t) * d.ldx + c0 + c4);
-        ushort4 o;
-        o.x = rb_f2bf(v.x > 0.f ? v.x : v.x * d.slope);
-        o.y = rb_f2bf(v.y > 0.f ? v.y : v.y * d.slope);
-        o.z = rb_f2bf(v.z > 0.f ? v.z : v.z * d.slope);
-        o.w = rb_f2bf(v.w > 0.f ? v.w : v.w * d.slope);
-        *reinterpret_cast<ushort4*>(xa + wr * XP + c4) = o;
+      // PER independent 16-byte loads per thread in flight before the first one is consumed (clamped addresses, no branches)
+      constexpr int Q4 = KC / 4, PER = 4;
+      const int total = win_rows * Q4;
+      for (int base = tid; base < total; base += RB_THREADS * PER) {
+        float4 v[PER];
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          int e = base + p * RB_THREADS;
+          e = e < total ? e : total - 1;
+          const int wr = e / Q4, c4 = (e % Q4) * 4;
+          const int t = wbase + wr;
+          const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+          v[p] = *reinterpret_cast<const float4*>(d.x + (size_t)(tile.seq_begin + tc) * d.ldx + c0 + c4);
+          if (t < 0 || t >= T) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          int e = base + p * RB_THREADS;
+          e = e < total ? e : total - 1;
+          const int wr = e / Q4, c4 = (e % Q4) * 4;
+          ushort4 o;
+          o.x = rb_f2bf(v[p].x > 0.f ? v[p].x : v[p].x * d.slope);
+          o.y = rb_f2bf(v[p].y > 0.f ? v[p].y : v[p].y * d.slope);
+          o.z = rb_f2bf(v[p].z > 0.f ? v[p].z : v[p].z * d.slope);
+          o.w = rb_f2bf(v[p].w > 0.f ? v[p].w : v[p].w * d.slope);
+          *reinterpret_cast<ushort4*>(xa + wr * XP + c4) = o;
+        }
       }
     }
     for (int tap = 0; tap < d.taps; ++tap, ++step) {

@@ -135,10 +135,11 @@ class Ops:
                    "tts_groupnorm")
         return y
 
-    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag):
-        tiles, n = rag.tiles(64)
+    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag, tile_rows=128):
+        """tile_rows 128: matrix-core kernel (fp32-input MFMA, exact fp32 products); 64: the VALU kernel."""
+        tiles, n = rag.tiles(tile_rows)
         capi.check(self.lib.tts_relpos_attention(qkv.data_ptr(), _ld(qkv), ptab.data_ptr(), pmax, bias_u.data_ptr(), bias_v.data_ptr(),
-                                                 ctx.data_ptr(), _ld(ctx), HEADS, DK, tiles.data_ptr(), n, 64, self.stream()),
+                                                 ctx.data_ptr(), _ld(ctx), HEADS, DK, tiles.data_ptr(), n, tile_rows, self.stream()),
                    "tts_relpos_attention")
         return ctx
 

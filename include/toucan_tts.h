@@ -135,7 +135,9 @@ int tts_groupnorm(const float* x, int32_t ldx, float* y, int32_t ldy, const floa
 /* Relative-position multi-head self-attention, flash style (scores never reach HBM):
  *   s[i,j] = ((q_i+u_h).k_j + (q_i+v_h).P[i-j]) / sqrt(dk); softmax over the utterance's keys; ctx = s.v
  * qkv: [rows, 3*h*dk] (q|k|v), ptab: [2*pmax-1, h*dk] with row (pmax-1+p) = linear_pos(pe(p)).
- * Layers/Attention.py:159-198 (rel_shift :138-157 folded into the index i-j), :66-92. */
+ * Layers/Attention.py:159-198 (rel_shift :138-157 folded into the index i-j), :66-92.
+ * tile_rows selects the implementation: 128 = matrix-core kernel (v_mfma_f32_32x32x2_f32, exact fp32 products),
+ * 64 = VALU kernel (one lane per query). */
 int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u,
                          const float* bias_v, float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk,
                          const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);

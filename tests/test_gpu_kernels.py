@@ -190,8 +190,9 @@ def test_layernorm_cln_l2_groupnorm(gpu, cpu):
         close(*both(gpu, cpu, gn), tol=5e-5)
 
 
-@pytest.mark.parametrize("lengths", [[7], [64], [65, 128, 1], [640, 333]])
-def test_relpos_attention(gpu, cpu, lengths):
+@pytest.mark.parametrize("lengths", [[7], [64], [65, 128, 1], [640, 333], [129, 31, 33]])
+@pytest.mark.parametrize("tile_rows", [64, 128])
+def test_relpos_attention(gpu, cpu, lengths, tile_rows):
     pmax = 700
 
     def run(ops, to):
@@ -199,7 +200,7 @@ def test_relpos_attention(gpu, cpu, lengths):
         qkv = to(rnd(rag.total_rows, 576, seed=1, scale=0.7))
         ptab = to(rnd(2 * pmax - 1, 192, seed=2, scale=0.5))
         ctx = to(torch.zeros(rag.total_rows, 192))
-        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag)
+        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, tile_rows)
     close(*both(gpu, cpu, run), tol=5e-5)
 
 

@@ -1,0 +1,52 @@
+"""Micro-benchmark of tts_resblock_step on the vocoder stage shapes (run on the MI355X box)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import ims_toucan_prosody_variance_amd  # noqa: F401
+from ims_toucan_prosody_variance_amd import capi, engine, packing
+from ims_toucan_prosody_variance_amd.ragged import Ragged
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=640)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ops = engine.Ops(dev)
+    filt = torch.from_numpy(packing.kaiser_sinc_filter12()).to(dev)
+    print(f"{'C':>4} {'k':>3} {'dil':>3} {'act':>6} {'us':>9} {'TFLOP/s':>8} {'GB/s(x+y)':>9}")
+    for C, mult in ((128, 48), (64, 192), (32, 384)):
+        rows = args.frames * mult
+        rag = Ragged([rows] * args.batch, dev)
+        R = rag.total_rows
+        x = torch.randn(R, C, device=dev)
+        y = torch.empty(R, C, device=dev)
+        sn = (torch.zeros(C, device=dev), torch.zeros(C, device=dev))
+        for k, dil in ((3, 1), (7, 3), (11, 5)):
+            rs = np.random.RandomState(0)
+            c1 = packing.pack_conv((rs.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32), np.zeros(C, np.float32), dev, dil=dil, bf16=True)
+            c2 = packing.pack_conv((rs.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32), np.zeros(C, np.float32), dev, dil=1, bf16=True)
+            for act, name in ((capi.PRE_LRELU, "lrelu"), (capi.PRE_SNAKE, "snake")):
+                run = lambda: ops.resblock_step(c1, c2, x, y, rag, act, 0.1, sn, sn, filt)
+                run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                us = 1e3 * e0.elapsed_time(e1) / args.reps
+                flops = 2 * 2.0 * R * C * C * k
+                print(f"{C:>4} {k:>3} {dil:>3} {name:>6} {us:9.1f} {flops / us / 1e6:8.1f} {2.0 * R * C * 4 / 1e9 / (us * 1e-6):9.0f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
