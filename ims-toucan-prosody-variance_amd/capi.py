@@ -39,6 +39,7 @@ class TtsConvDesc(C.Structure):
         ("aux", _p), ("ld_aux", _i),
         ("accumulate", _i),
         ("compute", _i),
+        ("io_flags", _i),
         ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
     ]
 
@@ -53,11 +54,13 @@ class TtsResblockDesc(C.Structure):
         ("act", _i), ("slope", _f),
         ("alpha1", _p), ("beta1", _p), ("alpha2", _p), ("beta2", _p), ("filt", _p),
         ("alpha", _f), ("res_scale", _f), ("accumulate", _i),
+        ("io_bf16", _i),
         ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
     ]
 
 
 RESBLOCK_TILE_ROWS = 224
+IO_X_BF16, IO_Y_BF16, IO_RES_BF16 = 1, 2, 4
 
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
 PROTOTYPES = {
@@ -77,8 +80,8 @@ PROTOTYPES = {
     "tts_prosody_control": (C.c_int, [_p, _i, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _p]),
     "tts_length_regulate": (C.c_int, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p, _i, _f, _p]),
     "tts_glow_invconv_actnorm": (C.c_int, [_p, _i, _i, _i, _p, _p, _p, _p]),
-    "tts_snake_aa": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _p]),
-    "tts_conv_post": (C.c_int, [_p, _i, _i, _p, _f, _i, _f, _p, _p, _i, _i, _p]),
+    "tts_snake_aa": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
+    "tts_conv_post": (C.c_int, [_p, _i, _i, _p, _f, _i, _f, _p, _p, _i, _i, _i, _p]),
     "tts_gather_rows": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _p]),
     "tts_axpby": (C.c_int, [_p, _i, _f, _p, _i, _f, _p, _i, _i, _i, _p]),
 }

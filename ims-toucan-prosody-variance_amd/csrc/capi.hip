@@ -36,8 +36,8 @@ int prosody_control(const float*, int, float*, float*, int*, const int*, const i
 int length_regulate(const float*, int, const float*, const float*, const float*, const float*, const float*, const float*,
                     const int*, const int*, const int*, const int*, int, int, int, int, float*, int, float*, int, float, hipStream_t);
 int glow_invconv_actnorm(float*, int, int, int, const float*, const float*, const float*, hipStream_t);
-int snake_aa(const float*, int, float*, int, const float*, const float*, const float*, int, const TtsTile*, int, int, hipStream_t);
-int conv_post(const float*, int, int, const float*, float, int, float, float*, const TtsTile*, int, int, hipStream_t);
+int snake_aa(const float*, int, float*, int, const float*, const float*, const float*, int, const TtsTile*, int, int, int, hipStream_t);
+int conv_post(const float*, int, int, const float*, float, int, float, float*, const TtsTile*, int, int, int, hipStream_t);
 int gather_rows(const float*, int, const int*, float*, int, int, int, hipStream_t);
 int resblock_step(const TtsResblockDesc& d, hipStream_t st);
 
@@ -128,13 +128,13 @@ int tts_glow_invconv_actnorm(float* x, int32_t ldx, int32_t rows, int32_t c, con
 }
 
 int tts_snake_aa(const float* x, int32_t ldx, float* y, int32_t ldy, const float* alpha, const float* beta, const float* filt, int32_t c,
-                 const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream) {
-  return tts::snake_aa(x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, ST(stream));
+                 const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, int32_t io_flags, tts_stream_t stream) {
+  return tts::snake_aa(x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, io_flags, ST(stream));
 }
 
 int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w, float bias, int32_t pre_act, float pre_slope, float* wav,
-                  const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream) {
-  return tts::conv_post(x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, ST(stream));
+                  const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, int32_t io_flags, tts_stream_t stream) {
+  return tts::conv_post(x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, io_flags, ST(stream));
 }
 
 int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst, int32_t n, int32_t c,

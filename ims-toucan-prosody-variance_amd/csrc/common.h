@@ -31,6 +31,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  const __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round to nearest even, NaN preserved
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __builtin_bit_cast(float, (unsigned int)u << 16); }
+
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

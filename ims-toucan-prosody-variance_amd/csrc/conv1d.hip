@@ -32,10 +32,7 @@ __device__ __forceinline__ float pre_activation(float v, int pre_act, float slop
   return v;
 }
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  const __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (round to nearest even, NaN preserved)
-  return __builtin_bit_cast(unsigned short, b);
-}
+__device__ __forceinline__ unsigned short f2bf(float f) { return f32_to_bf16(f); }
 
 template <bool BF16>
 struct Elem;
@@ -98,7 +95,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
 
   const int row_first = tile.row0 - d.pad_left;  // packed row of window row 0
-  const bool vec_ok = ((d.ldx & 3) == 0) && ((d.cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.x) & 15) == 0);
+  const bool x_bf16 = d.io_flags & TTS_IO_X_BF16;
+  const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // the input viewed as bf16
+  const bool vec_ok = ((d.ldx & 3) == 0) && ((d.cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.x) & (x_bf16 ? 7 : 15)) == 0);
   const ET* __restrict__ W = reinterpret_cast<const ET*>(d.w);
   const int n_chunks = (d.cin_pad + BK - 1) / BK;
   const int total_steps = n_chunks * d.taps;
@@ -166,7 +165,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         float o[8];
         const bool live = cg < d.cin && t0 + 7 >= 0 && t0 < T;
         if constexpr (SNAKE)
-          if (live) snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, expf(d.snake_alpha[cg]), 1.0f / (expf(d.snake_beta[cg]) + 1e-9f), o);
+          if (live) {
+            const float ea = expf(d.snake_alpha[cg]), ib = 1.0f / (expf(d.snake_beta[cg]) + 1e-9f);
+            if (x_bf16)
+              snake_rows_fn<8>([&](int q) { return bf16_to_f32(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, T, t0, f, ea, ib, o);
+            else
+              snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, ea, ib, o);
+          }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           if (wr0 + i < win_rows) xs[(wr0 + i) * XP + chl] = Elem<BF16>::cvt((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
@@ -188,7 +193,12 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           const bool ok = gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c4) < d.cin;
           const int grc = gr < tile.seq_begin ? tile.seq_begin : (gr >= tile.seq_end ? tile.seq_end - 1 : gr);
           const int cc = (c0 + c4) < d.cin ? (c0 + c4) : d.cin - 4;
-          v[p] = *reinterpret_cast<const float4*>(d.x + (size_t)grc * d.ldx + cc);
+          if (x_bf16) {  // 4 bf16 = 8 bytes
+            const uint2 raw = *reinterpret_cast<const uint2*>(xh + (size_t)grc * d.ldx + cc);
+            v[p] = make_float4(bf16_to_f32(raw.x & 0xFFFF), bf16_to_f32(raw.x >> 16), bf16_to_f32(raw.y & 0xFFFF), bf16_to_f32(raw.y >> 16));
+          } else {
+            v[p] = *reinterpret_cast<const float4*>(d.x + (size_t)grc * d.ldx + cc);
+          }
           if (!ok) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -208,7 +218,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         const int wr = e / kchunk, c = e % kchunk;
         const int gr = row_first + wr;
         float v = 0.f;
-        if (gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c) < d.cin) v = d.x[(size_t)gr * d.ldx + c0 + c];
+        if (gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c) < d.cin)
+          v = x_bf16 ? bf16_to_f32(xh[(size_t)gr * d.ldx + c0 + c]) : d.x[(size_t)gr * d.ldx + c0 + c];
         xs[wr * XP + c] = Elem<BF16>::cvt(pre_activation(v, d.pre_act, d.pre_slope));
       }
     }
@@ -299,10 +310,20 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           else if (d.act == TTS_ACT_TANH) v = tanhf(v);
         }
         v *= d.alpha;
-        if (d.res) v += d.res_scale * d.res[(size_t)row * d.ld_res + n];
-        float* yp = d.y + (size_t)row * d.ldy + n;
-        if (d.accumulate) v += *yp;
-        *yp = v;
+        if (d.res) {
+          const float rv = (d.io_flags & TTS_IO_RES_BF16) ? bf16_to_f32(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n])
+                                                          : d.res[(size_t)row * d.ld_res + n];
+          v += d.res_scale * rv;
+        }
+        if (d.io_flags & TTS_IO_Y_BF16) {
+          unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
+          if (d.accumulate) v += bf16_to_f32(*yp);
+          *yp = f32_to_bf16(v);
+        } else {
+          float* yp = d.y + (size_t)row * d.ldy + n;
+          if (d.accumulate) v += *yp;
+          *yp = v;
+        }
       }
     }
   }

@@ -8,7 +8,7 @@
 // Decomposition (512 threads = 8 wavefronts, one utterance per workgroup via the tile table):
 //   * output tile: BM = 224 rows; conv1 is evaluated on M1 = 256 rows (BM + 16 each side: conv2's halo <= 5 and the
 //     anti-alias filter's halo 6), wave w owns rows 32w..32w+31 and all C columns (C/32 accumulators of 32x32).
-//   * act1(x) window (M1 + 2*h1 rows, h1 = (k-1)/2*dil) is staged per 64-channel slab as bf16; the anti-aliased snake
+//   * act1(x) window (M1 + 2*h1 rows, h1 = (k-1)/2*dil, all C channels) is staged once as bf16; the anti-aliased snake
 //     is computed in registers while staging (snake.h), LeakyReLU element-wise.
 //   * conv1 accumulators (+bias) go to LDS as bf16 (t1, M1 x C); the second activation runs in place on t1
 //     (snake: every item first computes its 8 outputs into registers, barrier, then overwrites).
@@ -22,18 +22,16 @@
 
 namespace tts {
 
-__device__ __forceinline__ unsigned short rb_f2bf(float f) {
-  const __bf16 b = (__bf16)f;
-  return __builtin_bit_cast(unsigned short, b);
-}
-__device__ __forceinline__ float rb_bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned int)u << 16); }
+__device__ __forceinline__ unsigned short rb_f2bf(float f) { return f32_to_bf16(f); }
+__device__ __forceinline__ float rb_bf2f(unsigned short u) { return bf16_to_f32(u); }
 
 constexpr int RB_BM = 224, RB_M1 = 256, RB_LEAD = 16, RB_THREADS = 512;
 
 // waves per SIMD the register allocation must leave room for: 3 / 2 / 1 workgroups per CU (C = 32 / 64 / 128; LDS allows no more)
-template <int C>
-__global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void resblock_step_kernel(const TtsResblockDesc d) {
-  constexpr int KC = C < 64 ? C : 64;     // channels per slab
+// IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
+template <int C, bool IOB>
+__global__ __launch_bounds__(RB_THREADS, (C == 128 ? 2 : 4)) void resblock_step_kernel(const TtsResblockDesc d) {
+  constexpr int KC = C;                   // channels per weight slab = all of them: one step per tap, act1(x) staged once
   constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
   constexpr int TP = C + 8;               // t1 pitch
   constexpr int TN = C / 32;              // 32-column accumulators per wave
@@ -56,6 +54,7 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
   const int T = tile.seq_end - tile.seq_begin;
   const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
   const bool snake = d.act == TTS_PRE_SNAKE;
+  const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
   const int steps1 = NCH * d.taps, total_steps = 2 * steps1;
 
   uint4 wreg[UPT];
@@ -100,17 +99,61 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
     // window row j <-> local frame l0 - LEAD - h1 + j
     const int wbase = l0 - RB_LEAD - h1;
     if (snake) {
-      const int items = ((win_rows + 7) >> 3) * KC;
+      // anti-aliased snake while staging: item = (8*NCH1 window rows, channel), streamed so that only the first chunk pays the halo
+      constexpr int NCH1 = C == 32 ? 3 : 5, GR = 8 * NCH1;
+      const int items = ((win_rows + GR - 1) / GR) * KC;
       for (int it = tid; it < items; it += RB_THREADS) {
-        const int chl = it % KC, wr0 = (it / KC) * 8;
+        const int chl = it % KC, wr0 = (it / KC) * GR;
         const int cg = c0 + chl;
         const int t0 = wbase + wr0;
-        float o[8];
-        const bool live = t0 + 7 >= 0 && t0 < T;
-        if (live) snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, expf(d.alpha1[cg]), 1.0f / (expf(d.beta1[cg]) + 1e-9f), o);
+        const bool live = t0 + GR - 1 >= 0 && t0 < T;
+        if (live) {
+          const float ea = expf(d.alpha1[cg]), ib = 1.0f / (expf(d.beta1[cg]) + 1e-9f);
+          auto st = [&](int i, float v) {
+            if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = rb_f2bf((t0 + i >= 0 && t0 + i < T) ? v : 0.0f);
+          };
+          if constexpr (IOB)
+            snake_stream<NCH1>([&](int q) { return rb_bf2f(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, st, T, t0, f, ea, ib);
+          else
+            snake_stream<NCH1>([&](int q) { return d.x[(size_t)(tile.seq_begin + q) * d.ldx + cg]; }, st, T, t0, f, ea, ib);
+        } else {
+          for (int i = 0; i < GR; ++i)
+            if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = 0;
+        }
+      }
+    } else if constexpr (IOB) {
+      // bf16 input: 8 channels per 16-byte load; PER loads in flight per thread (clamped addresses, no branches)
+      constexpr int Q8 = KC / 8, PER = 4;
+      const int total = win_rows * Q8;
+      for (int base = tid; base < total; base += RB_THREADS * PER) {
+        uint4 v[PER];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = rb_f2bf((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
+        for (int p = 0; p < PER; ++p) {
+          int e = base + p * RB_THREADS;
+          e = e < total ? e : total - 1;
+          const int wr = e / Q8, c8 = (e % Q8) * 8;
+          const int t = wbase + wr;
+          const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+          v[p] = *reinterpret_cast<const uint4*>(xh + (size_t)(tile.seq_begin + tc) * d.ldx + c0 + c8);
+          if (t < 0 || t >= T) v[p] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+          int e = base + p * RB_THREADS;
+          e = e < total ? e : total - 1;
+          const int wr = e / Q8, c8 = (e % Q8) * 8;
+          const unsigned int w4[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+          uint4 o;
+          unsigned int* op = &o.x;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float lo = rb_bf2f(w4[q] & 0xFFFF), hi2 = rb_bf2f(w4[q] >> 16);
+            lo = lo > 0.f ? lo : lo * d.slope;
+            hi2 = hi2 > 0.f ? hi2 : hi2 * d.slope;
+            op[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
+          }
+          *reinterpret_cast<uint4*>(xa + wr * XP + c8) = o;
+        }
       }
     } else {
       // PER independent 16-byte loads per thread in flight before the first one is consumed (clamped addresses, no branches)
@@ -179,34 +222,37 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
   }
   __syncthreads();
   if (snake) {
-    // second anti-aliased snake, in place on t1: compute all outputs of this thread into registers, then overwrite
-    constexpr int ITEMS = (RB_M1 / 8) * C / RB_THREADS;  // C/16
-    float o[ITEMS][8];
+    // second anti-aliased snake, in place on t1: every thread first computes all its outputs into registers, then overwrites.
+    // item = (8*NCH2 rows, channel): 256 rows x C channels over 512 threads = C/2 values per thread
+    constexpr int NCH2 = C == 32 ? 2 : 4, GR = 8 * NCH2;
+    constexpr int ITEMS = (RB_M1 / GR) * C / RB_THREADS;
+    static_assert((RB_M1 / GR) * C % RB_THREADS == 0, "in-place snake items must tile the workgroup");
+    float o[ITEMS][GR];
+    const int base = l0 - RB_LEAD;  // local frame of t1 row 0
 #pragma unroll
     for (int q = 0; q < ITEMS; ++q) {
       const int it = tid + q * RB_THREADS;
-      const int chn = it % C, i0 = (it / C) * 8;
-      const int t0 = l0 - RB_LEAD + i0;
-      const bool live = t0 + 7 >= 0 && t0 < T;
+      const int chn = it % C, i0 = (it / C) * GR;
+      const int t0 = base + i0;
+      const bool live = t0 + GR - 1 >= 0 && t0 < T;
+#pragma unroll
+      for (int i = 0; i < GR; ++i) o[q][i] = 0.0f;
       if (live) {
-        const int base = l0 - RB_LEAD;  // local frame of t1 row 0
-        snake_rows_fn<8>([&](int q2) {
+        snake_stream<NCH2>([&](int q2) {
           int i = q2 - base;
           i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);  // only reached by rows whose outputs are not consumed
           return rb_bf2f(t1[i * TP + chn]);
-        }, T, t0, f, expf(d.alpha2[chn]), 1.0f / (expf(d.beta2[chn]) + 1e-9f), o[q]);
+        }, [&](int i, float v) { o[q][i] = (t0 + i >= 0 && t0 + i < T) ? v : 0.0f; }, T, t0, f, expf(d.alpha2[chn]),
+                           1.0f / (expf(d.beta2[chn]) + 1e-9f));
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (!(live && t0 + i >= 0 && t0 + i < T)) o[q][i] = 0.0f;
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < ITEMS; ++q) {
       const int it = tid + q * RB_THREADS;
-      const int chn = it % C, i0 = (it / C) * 8;
+      const int chn = it % C, i0 = (it / C) * GR;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t1[(i0 + i) * TP + chn] = rb_f2bf(o[q][i]);
+      for (int i = 0; i < GR; ++i) t1[(i0 + i) * TP + chn] = rb_f2bf(o[q][i]);
     }
   }
 
@@ -233,6 +279,45 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
   }
 
   // ------------------------------------------------------------------ epilogue
+  if constexpr (IOB) {
+    // bf16 tensors: the fp32 tile alpha*(conv2 + b2) goes through LDS (it overlays xa/t1/ws, all dead now) so that the
+    // residual read and the output write are whole 16-byte row segments instead of 2-byte column accesses
+    float* ot = reinterpret_cast<float*>(lds_raw);  // [BM][C]
+    __syncthreads();                                // every wave is done reading t1 / ws
+    if (wave < RB_BM / 32) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = j * 32 + lrow;
+        const float b2 = d.b2[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * C + n] = d.alpha * (acc[j][r] + b2);
+      }
+    }
+    __syncthreads();
+    unsigned short* yh = reinterpret_cast<unsigned short*>(d.y);
+    constexpr int Q8 = C / 8;
+    for (int e = tid; e < RB_BM * Q8; e += RB_THREADS) {
+      const int orow = e / Q8, c8 = (e % Q8) * 8;
+      const int row = tile.row0 + orow;
+      if (row >= tile.seq_end) break;
+      const uint4 xr = *reinterpret_cast<const uint4*>(xh + (size_t)row * d.ldx + c8);
+      uint4 yr = make_uint4(0, 0, 0, 0);
+      if (d.accumulate) yr = *reinterpret_cast<const uint4*>(yh + (size_t)row * d.ldy + c8);
+      const float4 o0 = *reinterpret_cast<const float4*>(ot + orow * C + c8), o1 = *reinterpret_cast<const float4*>(ot + orow * C + c8 + 4);
+      const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+      const unsigned int xw[4] = {xr.x, xr.y, xr.z, xr.w}, yw[4] = {yr.x, yr.y, yr.z, yr.w};
+      uint4 out;
+      unsigned int* op = &out.x;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float lo = ov[2 * q] + d.res_scale * rb_bf2f(xw[q] & 0xFFFF), hi2 = ov[2 * q + 1] + d.res_scale * rb_bf2f(xw[q] >> 16);
+        if (d.accumulate) { lo += rb_bf2f(yw[q] & 0xFFFF); hi2 += rb_bf2f(yw[q] >> 16); }
+        op[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
+      }
+      *reinterpret_cast<uint4*>(yh + (size_t)row * d.ldy + c8) = out;
+    }
+    return;
+  }
   if (wave < RB_BM / 32) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -251,14 +336,15 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
   }
 }
 
-template <int C>
+template <int C, bool IOB>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
-  constexpr int KC = C < 64 ? C : 64;
+  constexpr int KC = C;
   const int h1 = (d.taps - 1) / 2 * d.dil;
   const size_t xa = (((size_t)(RB_M1 + 2 * h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
-  const size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * KC * C) * 2;
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * KC * C) * 2;
+  if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
-  auto k = resblock_step_kernel<C>;
+  auto k = resblock_step_kernel<C, IOB>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(d.n_tiles), dim3(RB_THREADS), lds, st, d);
   return launch_status("resblock_step");
@@ -273,11 +359,19 @@ int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.act == TTS_PRE_LRELU || d.act == TTS_PRE_SNAKE, "resblock_step: act must be LRELU or SNAKE");
   TTS_CHECK_ARG(d.act != TTS_PRE_SNAKE || (d.alpha1 && d.beta1 && d.alpha2 && d.beta2 && d.filt), "resblock_step: snake parameters missing");
   TTS_CHECK_ARG((d.ldx & 3) == 0 && ((uintptr_t)d.x & 15) == 0, "resblock_step: x must be 16-byte aligned rows");
+  TTS_CHECK_ARG(!d.io_bf16 || ((d.ldx & 7) == 0 && (d.ldy & 7) == 0 && ((uintptr_t)d.y & 15) == 0), "resblock_step: bf16 rows must be 16-byte aligned");
   if (d.n_tiles == 0) return TTS_OK;
+  if (d.io_bf16) {
+    switch (d.c) {
+      case 32: return launch_rb<32, true>(d, st);
+      case 64: return launch_rb<64, true>(d, st);
+      default: return launch_rb<128, true>(d, st);
+    }
+  }
   switch (d.c) {
-    case 32: return launch_rb<32>(d, st);
-    case 64: return launch_rb<64>(d, st);
-    default: return launch_rb<128>(d, st);
+    case 32: return launch_rb<32, false>(d, st);
+    case 64: return launch_rb<64, false>(d, st);
+    default: return launch_rb<128, false>(d, st);
   }
 }
 

@@ -269,7 +269,7 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const float* __restrict__ filt, int c, const TtsTile* __restrict__ tiles,
-                                                       int tile_rows) {
+                                                       int tile_rows, int io_flags) {
   const TtsTile t = tiles[blockIdx.x];
   // work item = (group of ROWS frames, channel); consecutive threads take consecutive channels, so a wavefront
   // reads 256 contiguous bytes per row (two 128-byte rows when c == 32).  The 2x-rate signal lives in registers only.
@@ -285,21 +285,30 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
   const float ea = expf(alpha[ch]);
   const float inv_b = 1.0f / (expf(beta[ch]) + 1e-9f);
   float out[ROWS];
-  snake_rows<ROWS>(x, ldx, ch, t.seq_begin, t.seq_end - t.seq_begin, r0 - t.seq_begin, f, ea, inv_b, out);
+  if (io_flags & TTS_IO_X_BF16) {
+    const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(x);
+    snake_rows_fn<ROWS>([&](int q) { return bf16_to_f32(xh[(size_t)(t.seq_begin + q) * ldx + ch]); }, t.seq_end - t.seq_begin,
+                        r0 - t.seq_begin, f, ea, inv_b, out);
+  } else {
+    snake_rows<ROWS>(x, ldx, ch, t.seq_begin, t.seq_end - t.seq_begin, r0 - t.seq_begin, f, ea, inv_b, out);
+  }
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
     if (r0 + i >= t.seq_end) break;
-    y[(size_t)(r0 + i) * ldy + ch] = out[i];
+    if (io_flags & TTS_IO_Y_BF16)
+      reinterpret_cast<unsigned short*>(y)[(size_t)(r0 + i) * ldy + ch] = f32_to_bf16(out[i]);
+    else
+      y[(size_t)(r0 + i) * ldy + ch] = out[i];
   }
 }
 
 int snake_aa(const float* x, int ldx, float* y, int ldy, const float* alpha, const float* beta, const float* filt, int c,
-             const TtsTile* tiles, int n_tiles, int tile_rows, hipStream_t st) {
+             const TtsTile* tiles, int n_tiles, int tile_rows, int io_flags, hipStream_t st) {
   TTS_CHECK_ARG(tile_rows % 8 == 0, "snake_aa: tile_rows must be a multiple of 8");
   if (n_tiles == 0) return TTS_OK;
   const int items = (tile_rows / 8) * c;
   dim3 grid(n_tiles, (items + 255) / 256), block(256);
-  hipLaunchKernelGGL(snake_aa_kernel<8>, grid, block, 0, st, x, ldx, y, ldy, alpha, beta, filt, c, tiles, tile_rows);
+  hipLaunchKernelGGL(snake_aa_kernel<8>, grid, block, 0, st, x, ldx, y, ldy, alpha, beta, filt, c, tiles, tile_rows, io_flags);
   return launch_status("snake_aa");
 }
 
@@ -310,7 +319,7 @@ int snake_aa(const float* x, int ldx, float* y, int ldy, const float* alpha, con
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, int ldx, int cin, const float* __restrict__ w,
                                                         float bias, int pre_act, float pre_slope, float* __restrict__ wav,
-                                                        const TtsTile* __restrict__ tiles) {
+                                                        const TtsTile* __restrict__ tiles, int io_flags) {
   extern __shared__ float lds[];
   const TtsTile t = tiles[blockIdx.x];
   const int pitch = cin + 1;
@@ -321,7 +330,8 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int wr = e / cin, ch = e % cin;
     const int r = t.row0 - 3 + wr;
     float v = 0.f;
-    if (r >= t.seq_begin && r < t.seq_end) v = x[(size_t)r * ldx + ch];
+    if (r >= t.seq_begin && r < t.seq_end)
+      v = (io_flags & TTS_IO_X_BF16) ? bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[(size_t)r * ldx + ch]) : x[(size_t)r * ldx + ch];
     if (pre_act == TTS_PRE_LRELU) v = v > 0.f ? v : v * pre_slope;
     xs[wr * pitch + ch] = v;
   }
@@ -338,12 +348,12 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
 }
 
 int conv_post(const float* x, int ldx, int cin, const float* w, float bias, int pre_act, float pre_slope, float* wav,
-              const TtsTile* tiles, int n_tiles, int tile_rows, hipStream_t st) {
+              const TtsTile* tiles, int n_tiles, int tile_rows, int io_flags, hipStream_t st) {
   TTS_CHECK_ARG(tile_rows == 256, "conv_post: tile table must use 256 rows, got %d", tile_rows);
   TTS_CHECK_ARG(cin > 0 && cin <= 64, "conv_post: cin %d unsupported", cin);
   if (n_tiles == 0) return TTS_OK;
   size_t lds = (size_t)(262 * (cin + 1) + 7 * cin) * sizeof(float);
-  hipLaunchKernelGGL(conv_post_kernel, dim3(n_tiles), dim3(256), lds, st, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles);
+  hipLaunchKernelGGL(conv_post_kernel, dim3(n_tiles), dim3(256), lds, st, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, io_flags);
   return launch_status("conv_post");
 }
 

@@ -73,6 +73,69 @@ __device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const 
   }
 }
 
+// Streaming form: 8*NCH consecutive frames starting at local frame t0.  Chunk c reuses the last 12 input frames and the
+// last 10 2x-rate samples of chunk c-1 (they are exactly the halo it would otherwise recompute), so only the first chunk
+// pays the (26 samples / 8 frames) halo overhead of snake_rows_fn; with NCH = 5 the up-sampler + sine work per frame drops
+// from 3.25 to 2.25 samples.  store(i, v) receives frame t0+i (callers mask frames outside [0, T)).
+template <int NCH, class LoadFn, class StoreFn>
+__device__ __forceinline__ void snake_stream(LoadFn load, StoreFn store, int T, int t0, const float (&f)[12], float ea, float inv_b) {
+  float xin[20];  // x[tc-6 .. tc+13] of the current chunk
+  float s[26];    // s[m] <-> n = 2*tc - 5 + m
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int tc = t0 + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+      if (c > 0 && i < 12) {
+        xin[i] = xin[i + 8];  // ascending i: the source slot is overwritten only later in this loop
+      } else {
+        int q = tc - 6 + i;
+        q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
+        xin[i] = load(q);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 26; ++m) {
+      if (c > 0 && m < 10) {
+        s[m] = s[m + 16];  // positions 2tc-5 .. 2tc+4 were the tail of the previous chunk (already edge-corrected)
+      } else {
+        const int qi = 3 + ((m + 1) >> 1);
+        float u = 0.f;
+        if (((m + 1) & 1) == 0) {
+#pragma unroll
+          for (int d = -3; d <= 2; ++d) u = fmaf(xin[qi + d], f[5 - 2 * d], u);
+        } else {
+#pragma unroll
+          for (int d = -2; d <= 3; ++d) u = fmaf(xin[qi + d], f[6 - 2 * d], u);
+        }
+        u *= 2.0f;
+        s[m] = fmaf(inv_b, sin_sq(u * ea), u);
+      }
+    }
+    const int nbase = 2 * tc - 5;
+    if (nbase < 0 || nbase + 25 > 2 * T - 1) {
+      float s_lo = 0.f, s_hi = 0.f;
+#pragma unroll
+      for (int m = 0; m < 26; ++m) {
+        if (nbase + m == 0) s_lo = s[m];
+        if (nbase + m == 2 * T - 1) s_hi = s[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 26; ++m) {
+        if (nbase + m < 0) s[m] = s_lo;
+        if (nbase + m > 2 * T - 1) s[m] = s_hi;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
+      store(8 * c + i, a);
+    }
+  }
+}
+
 // The same on a packed fp32 tensor in global memory: channel ch of the utterance starting at packed row seq_begin.
 template <int ROWS>
 __device__ __forceinline__ void snake_rows(const float* __restrict__ x, int ldx, int ch, int seq_begin, int T, int t0,

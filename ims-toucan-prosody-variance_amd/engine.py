@@ -25,6 +25,10 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _is_bf16(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
 def _ld(t):
     if t is None:
         return 0
@@ -74,6 +78,8 @@ class Ops:
         d.aux, d.ld_aux = _ptr(aux), _ld(aux)
         d.accumulate = 1 if accumulate else 0
         d.compute = COMPUTE_BF16 if use_bf16 else COMPUTE_F32
+        # bf16 tensors in HBM are recognised by dtype (strides are already in elements)
+        d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0)
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, cw.tile_rows
         tm = self.timer
         if tm is not None and tm.wants(cw, d.compute):
@@ -100,6 +106,8 @@ class Ops:
             d.alpha2, d.beta2 = snake2[0].data_ptr(), snake2[1].data_ptr()
             d.filt = filt.data_ptr()
         d.alpha, d.res_scale, d.accumulate = alpha, res_scale, 1 if accumulate else 0
+        assert _is_bf16(x) == _is_bf16(y)
+        d.io_bf16 = 1 if _is_bf16(x) else 0
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, capi.RESBLOCK_TILE_ROWS
         tm = self.timer
         if tm is not None and tm.wants_name("resblock_step<%d>" % c1.cin):
@@ -173,14 +181,15 @@ class Ops:
 
     def snake_aa(self, x, y, alpha, beta, filt, c, rag):
         tiles, n = rag.tiles(64)
+        flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0)
         capi.check(self.lib.tts_snake_aa(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), alpha.data_ptr(), beta.data_ptr(), filt.data_ptr(), c,
-                                         tiles.data_ptr(), n, 64, self.stream()), "tts_snake_aa")
+                                         tiles.data_ptr(), n, 64, flags, self.stream()), "tts_snake_aa")
         return y
 
     def conv_post(self, x, cin, w, bias, pre, slope, wav, rag):
         tiles, n = rag.tiles(256)
         capi.check(self.lib.tts_conv_post(x.data_ptr(), _ld(x), cin, w.data_ptr(), bias, pre, slope, wav.data_ptr(), tiles.data_ptr(), n,
-                                          256, self.stream()), "tts_conv_post")
+                                          256, capi.IO_X_BF16 if _is_bf16(x) else 0, self.stream()), "tts_conv_post")
         return wav
 
     def gather_rows(self, src, idx, dst):
@@ -518,7 +527,7 @@ class VocoderEngine:
     KS = (3, 7, 11)
     DIL = (1, 3, 5)
 
-    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False, fuse_step=None):
+    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False, fuse_step=None, store_bf16=None):
         assert kind in ("bigvgan", "hifigan")
         self.kind = kind
         # BigVGAN: run the anti-aliased snake inside the convs' input staging (TTS_PRE_SNAKE, no extra HBM round trip) or as
@@ -527,6 +536,7 @@ class VocoderEngine:
         self.fuse_snake = fuse_snake
         # bf16 only: one fused kernel per residual dilation step (tts_resblock_step) for the stages with C <= 128
         self.fuse_step = bf16 if fuse_step is None else (fuse_step and bf16)
+        self.store_bf16 = self.fuse_step if store_bf16 is None else (store_bf16 and self.fuse_step)
         self.ops = Ops(device)
         self.device = self.ops.device
         self.compute = COMPUTE_BF16 if bf16 else COMPUTE_F32
@@ -573,15 +583,18 @@ class VocoderEngine:
         for i, (u, k) in enumerate(self.UP):
             ch //= 2
             # transposed conv as a 3-tap polyphase conv; [R, u*ch] re-viewed as [R*u, ch]
-            y = ops.conv(self.ups[i], x, ops.empty(R, u * ch), rag, pre=PRE_NONE if big else PRE_LRELU, pre_slope=0.1, compute=cp)
+            # stages that run the fused residual step keep their residual stream as bf16 in HBM (bandwidth-bound kernels)
+            fused = self.fuse_step and ch <= 128
+            sdt = torch.bfloat16 if (fused and self.store_bf16) else torch.float32
+            y = ops.conv(self.ups[i], x, ops.empty(R, u * ch, dtype=sdt), rag, pre=PRE_NONE if big else PRE_LRELU, pre_slope=0.1, compute=cp)
             R, rag = R * u, rag.scaled(u)
             xs = y.view(R, ch)
-            stage_out = ops.empty(R, ch)
-            t1 = ops.empty(R, ch)
-            t2, sa = (ops.empty(R, ch), ops.empty(R, ch)) if (big and not self.fuse_snake) else (None, None)
+            stage_out = ops.empty(R, ch, dtype=sdt)
+            t1 = None if fused else ops.empty(R, ch)
+            t2, sa = (ops.empty(R, ch), ops.empty(R, ch)) if (big and not self.fuse_snake and not fused) else (None, None)
             for j in range(3):
                 cur = xs
-                bufs = [ops.empty(R, ch), ops.empty(R, ch)]
+                bufs = [ops.empty(R, ch, dtype=sdt), ops.empty(R, ch, dtype=sdt)]
                 for dd in range(3):
                     c1, c2 = self.blocks[i][j][dd]
                     last = dd == 2
@@ -615,7 +628,7 @@ class VocoderEngine:
                                  res_scale=1.0 / 3.0, accumulate=(j > 0), compute=cp)
             x = stage_out
             if taps is not None:
-                taps[f"voc_stage{i}"] = x.clone()
+                taps[f"voc_stage{i}"] = x.float()
         wav = ops.empty(R)
         if big:
             t = ops.snake_aa(x, ops.empty(R, ch), *self.post_snake, self.filt, ch, rag)

@@ -49,6 +49,9 @@ typedef struct {
 #define TTS_ACT_NONE 0
 #define TTS_ACT_RELU 1
 #define TTS_ACT_TANH 2
+#define TTS_IO_X_BF16 1
+#define TTS_IO_Y_BF16 2
+#define TTS_IO_RES_BF16 4
 #define TTS_PRE_NONE 0
 #define TTS_PRE_LRELU 1
 #define TTS_PRE_SNAKE 2 /* anti-aliased SnakeBeta (see tts_snake_aa) applied while the input window is staged */
@@ -81,6 +84,7 @@ typedef struct {
   const float* aux;    int32_t ld_aux;    /* COUPLING: x1 */
   int32_t accumulate;
   int32_t compute;     /* 0: fp32 MFMA (exact fp32 fma chain); 1: bf16 MFMA, fp32 accumulate */
+  int32_t io_flags;    /* TTS_IO_* bits: which of x / y / res are bf16 tensors in HBM (ld* then count bf16 elements) */
   const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows; /* tile_rows must match the kernel's BM */
 } TtsConvDesc;
 
@@ -108,6 +112,7 @@ typedef struct {
   int32_t act; float slope;
   const float* alpha1; const float* beta1; const float* alpha2; const float* beta2; const float* filt;
   float alpha, res_scale; int32_t accumulate;
+  int32_t io_bf16; /* 1: x and y are bf16 tensors in HBM (halves the traffic of this bandwidth-bound step) */
   const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows;
 } TtsResblockDesc;
 
@@ -174,13 +179,13 @@ int tts_glow_invconv_actnorm(float* x, int32_t ldx, int32_t rows, int32_t c, con
  * BigVGAN/Snake.py:56-69 + alias_free_torch Activation1d (third party, PARITY UNPINNED - see DESIGN.md). */
 int tts_snake_aa(const float* x, int32_t ldx, float* y, int32_t ldy, const float* alpha, const float* beta,
                  const float* filt /*[12]*/, int32_t c, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
-                 tts_stream_t stream);
+                 int32_t io_flags /* TTS_IO_X_BF16 | TTS_IO_Y_BF16 */, tts_stream_t stream);
 
 /* Final vocoder conv: wav[r] = tanh(b + sum_j sum_ci pre(x[r+j-3, ci]) w[j][ci]); pre = LeakyReLU(slope) or none.
  * InferenceAvocodo.py:52-59, InferenceBigVGAN.py:92-95. */
 int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w /*[7][cin]*/, float bias, int32_t pre_act,
                   float pre_slope, float* wav, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
-                  tts_stream_t stream);
+                  int32_t io_flags /* TTS_IO_X_BF16 */, tts_stream_t stream);
 
 /* Elementwise helper: y = a*x + b*z (z may be NULL), rows x c with strides. */
 int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz, float b, float* y, int32_t ldy,

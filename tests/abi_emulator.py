@@ -51,6 +51,22 @@ def _bf16_round(a):
     return r.astype(np.uint32).view(np.float32)
 
 
+def _load(ptr, r0, r1, cols, ld, bf16=False):
+    """rows [r0, r1) of a strided tensor as float32 (bf16 tensors are widened)."""
+    if bf16:
+        raw = _mat(ptr, r1, cols, ld, np.uint16)[r0:r1]
+        return (raw.astype(np.uint32) << 16).view(np.float32)
+    return _mat(ptr, r1, cols, ld)[r0:r1].astype(np.float32)
+
+
+def _store(ptr, r0, r1, cols, ld, values, bf16=False):
+    if bf16:
+        v = _bf16_round(np.ascontiguousarray(values, dtype=np.float32))
+        _mat(ptr, r1, cols, ld, np.uint16)[r0:r1] = (v.view(np.uint32) >> 16).astype(np.uint16)
+    else:
+        _mat(ptr, r1, cols, ld)[r0:r1] = values
+
+
 def _snake_seq(X, alpha, beta, filt):
     """Activation1d(SnakeBeta) on one utterance X [T, c] (fp64): replicate pad, 2x transposed conv, snake, 2x decimation."""
     T, c = X.shape
@@ -108,7 +124,7 @@ class Emulator:
         bias = _arr(d.bias, d.cout * (2 if dual else 1)) if d.bias else None
         for sb, se, sid in _seqs_from_tiles(t):
             n = se - sb
-            x = _mat(d.x, se, d.cin, d.ldx)[sb:se].astype(np.float32)
+            x = _load(d.x, sb, se, d.cin, d.ldx, d.io_flags & capi.IO_X_BF16)
             if d.pre_act == capi.PRE_LRELU:
                 x = np.where(x > 0, x, x * np.float32(d.pre_slope))
             elif d.pre_act == capi.PRE_SNAKE:
@@ -151,11 +167,10 @@ class Emulator:
                     v = np.tanh(v.astype(np.float64))
             v = (np.asarray(v, dtype=np.float32) * np.float32(d.alpha)).astype(np.float32)
             if d.res:
-                v = v + np.float32(d.res_scale) * _mat(d.res, se, d.cout, d.ld_res)[sb:se]
-            y = _mat(d.y, se, d.cout, d.ldy)
+                v = v + np.float32(d.res_scale) * _load(d.res, sb, se, d.cout, d.ld_res, d.io_flags & capi.IO_RES_BF16)
             if d.accumulate:
-                v = v + y[sb:se]
-            y[sb:se] = v
+                v = v + _load(d.y, sb, se, d.cout, d.ldy, d.io_flags & capi.IO_Y_BF16)
+            _store(d.y, sb, se, d.cout, d.ldy, v, d.io_flags & capi.IO_Y_BF16)
         return 0
 
     def tts_resblock_step(self, dref, stream):
@@ -187,7 +202,7 @@ class Emulator:
             return sum(vp[j * dil:j * dil + n] @ w[j] for j in range(k))
 
         for sb, se, sid in _seqs_from_tiles(_tiles(d.tiles, d.n_tiles)):
-            x = _mat(d.x, se, C_, d.ldx)[sb:se].astype(np.float64)
+            x = _load(d.x, sb, se, C_, d.ldx, d.io_bf16).astype(np.float64)
             a1 = _bf16_round(act(x, d.alpha1, d.beta1).astype(np.float32)).astype(np.float64)
             t = conv(a1, w1, d.dil) + b1
             if snake:
@@ -196,10 +211,9 @@ class Emulator:
             else:
                 a2 = _bf16_round(act(t, None, None).astype(np.float32)).astype(np.float64)
             v = np.float32(d.alpha) * (conv(a2, w2, 1) + b2).astype(np.float32) + np.float32(d.res_scale) * x.astype(np.float32)
-            y = _mat(d.y, se, C_, d.ldy)
             if d.accumulate:
-                v = v + y[sb:se]
-            y[sb:se] = v.astype(np.float32)
+                v = v + _load(d.y, sb, se, C_, d.ldy, d.io_bf16)
+            _store(d.y, sb, se, C_, d.ldy, v.astype(np.float32), d.io_bf16)
         return 0
 
     def tts_layernorm(self, x, ldx, y, ldy, gamma, beta, rows, c, eps, stream):
@@ -342,19 +356,20 @@ class Emulator:
         X[:] = ((z - _arr(an_bias, c)) * np.exp(-_arr(an_logs, c).astype(np.float64))).astype(np.float32)
         return 0
 
-    def tts_snake_aa(self, x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, stream):
+    def tts_snake_aa(self, x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, io_flags, stream):
         self._count("snake_aa")
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
-            X = _mat(x, se, c, ldx)[sb:se].astype(np.float64)
-            _mat(y, se, c, ldy)[sb:se] = _snake_seq(X, _arr(alpha, c), _arr(beta, c), _arr(filt, 12)).astype(np.float32)
+            X = _load(x, sb, se, c, ldx, io_flags & capi.IO_X_BF16).astype(np.float64)
+            out = _snake_seq(X, _arr(alpha, c), _arr(beta, c), _arr(filt, 12)).astype(np.float32)
+            _store(y, sb, se, c, ldy, out, io_flags & capi.IO_Y_BF16)
         return 0
 
-    def tts_conv_post(self, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, stream):
+    def tts_conv_post(self, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, io_flags, stream):
         self._count("conv_post")
         W = _mat(w, 7, cin, cin).astype(np.float64)
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
             n = se - sb
-            X = _mat(x, se, cin, ldx)[sb:se].astype(np.float64)
+            X = _load(x, sb, se, cin, ldx, io_flags & capi.IO_X_BF16).astype(np.float64)
             if pre_act == capi.PRE_LRELU:
                 X = np.where(X > 0, X, X * pre_slope)
             xp = np.zeros((n + 6, cin))

@@ -116,7 +116,8 @@ def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compu
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 225]), (32, 11, 5, [700, 30]), (64, 7, 3, [224, 449, 1]), (64, 11, 5, [300]),
                                              (128, 3, 1, [500, 17]), (128, 11, 5, [260, 100]), (128, 7, 1, [2, 223])])
 @pytest.mark.parametrize("act", [capi.PRE_LRELU, capi.PRE_SNAKE])
-def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act):
+@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16])
+def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act, store):
     """tts_resblock_step against the emulator (same bf16 rounding points) on ragged batches incl. tile-boundary lengths."""
     w1 = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
     w2 = rnd(c, c, k, seed=2, scale=1.0 / np.sqrt(c * k)).numpy()
@@ -127,15 +128,38 @@ def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act):
         R = rag.total_rows
         c1 = packing.pack_conv(w1, b1, ops.device, dil=dil, bf16=True)
         c2 = packing.pack_conv(w2, b2, ops.device, dil=1, bf16=True)
-        x = to(rnd(R, c, seed=5))
-        y = to(rnd(R, c, seed=6))
+        x = to(rnd(R, c, seed=5).to(store))
+        y = to(rnd(R, c, seed=6).to(store))
         sn1 = (to(rnd(c, seed=7, scale=0.3)), to(rnd(c, seed=8, scale=0.3)))
         sn2 = (to(rnd(c, seed=9, scale=0.3)), to(rnd(c, seed=10, scale=0.3)))
         filt = to(torch.from_numpy(packing.kaiser_sinc_filter12()))
         return ops.resblock_step(c1, c2, x, y, rag, act, 0.1, sn1, sn2, filt, alpha=1.0 / 3.0, res_scale=1.0 / 3.0, accumulate=True)
 
     g, cc = both(gpu, cpu, run)
-    close(g, cc, 1e-2)
+    close(g, cc, 1e-2 if store == torch.float32 else 2e-2)
+
+
+def test_conv1d_bf16_tensors_in_hbm(gpu, cpu):
+    """TTS_IO_*_BF16: x / y / res stored as bf16 (transposed-conv outputs and residual streams of the bf16 vocoder)."""
+    w = rnd(64, 64, 3, seed=1, scale=0.1).numpy()
+
+    def run(ops, to):
+        rag = Ragged([300, 17], ops.device, align=2)
+        R = rag.total_rows
+        cw = packing.pack_conv(w, rnd(64, seed=2, scale=0.1).numpy(), ops.device, bf16=True)
+        x = to(rnd(R, 64, seed=3).to(torch.bfloat16))
+        y = to(rnd(R, 64, seed=4).to(torch.bfloat16))
+        res = to(rnd(R, 64, seed=5).to(torch.bfloat16))
+        sn = (to(rnd(64, seed=6, scale=0.3)), to(rnd(64, seed=7, scale=0.3)), to(torch.from_numpy(packing.kaiser_sinc_filter12())))
+        ops.conv(cw, x, y, rag, pre=capi.PRE_SNAKE, snake=sn, res=res, accumulate=True, compute=capi.COMPUTE_BF16)
+        y2 = to(torch.zeros(R, 64))
+        ops.conv(cw, x, y2, rag, pre=capi.PRE_LRELU, pre_slope=0.1, res=res, compute=capi.COMPUTE_BF16)  # bf16 in, fp32 out
+        s_out = to(torch.zeros(R, 64))
+        ops.snake_aa(x, s_out, sn[0], sn[1], sn[2], 64, rag)
+        return torch.cat([y.float(), y2, s_out])
+
+    g, cc = both(gpu, cpu, run)
+    close(g, cc, 2e-2)
 
 
 def test_conv1d_rows_outside_utterances_are_untouched(gpu):

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=640)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops = engine.Ops(dev)
@@ -26,8 +27,9 @@ def main():
         rows = args.frames * mult
         rag = Ragged([rows] * args.batch, dev)
         R = rag.total_rows
-        x = torch.randn(R, C, device=dev)
-        y = torch.empty(R, C, device=dev)
+        sdt = torch.bfloat16 if args.store == "bf16" else torch.float32
+        x = torch.randn(R, C, device=dev).to(sdt)
+        y = torch.empty(R, C, device=dev, dtype=sdt)
         sn = (torch.zeros(C, device=dev), torch.zeros(C, device=dev))
         for k, dil in ((3, 1), (7, 3), (11, 5)):
             rs = np.random.RandomState(0)
