@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 
   uint4 wreg[NH][UPT];
   // 16-byte unit u of the slab of (chunk c0, tap): where it lives in global memory and in the LDS slab
-  auto load_slab = [&](int c0, int tap, int kchunk) {
+  auto load_slab = [&](int c0, int tap, int kchunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         wreg[h][q] = ok ? v : make_uint4(0, 0, 0, 0);
       }
   };
-  auto store_slab = [&](int buf) {
+  auto store_slab = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll

@@ -27,10 +27,40 @@ __device__ __forceinline__ float rb_bf2f(unsigned short u) { return bf16_to_f32(
 
 constexpr int RB_BM = 224, RB_M1 = 256, RB_LEAD = 16, RB_THREADS = 512;
 
+// register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
+// unconditional (clamped) loads, so the prefetch is not fenced by a branch
+template <int UNITS, int UPT>
+struct RbSlab {
+  static_assert(UPT >= 1 && UPT <= 4, "slab register staging holds at most 4 units per thread");
+  uint4 r0, r1, r2, r3;
+  static __device__ __forceinline__ uint4 ld(const unsigned short* __restrict__ src, int tid, int q) {
+    int u = tid + q * 512;
+    u = u < UNITS ? u : UNITS - 1;
+    return *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
+  }
+  static __device__ __forceinline__ void st(unsigned short* dst, int tid, int q, const uint4& v) {
+    const int u = tid + q * 512;
+    if (u < UNITS) *reinterpret_cast<uint4*>(dst + (size_t)u * 8) = v;
+  }
+  __device__ __forceinline__ void load(const unsigned short* __restrict__ src, int tid) {
+    r0 = ld(src, tid, 0);
+    if constexpr (UPT > 1) r1 = ld(src, tid, 1);
+    if constexpr (UPT > 2) r2 = ld(src, tid, 2);
+    if constexpr (UPT > 3) r3 = ld(src, tid, 3);
+  }
+  __device__ __forceinline__ void store(unsigned short* dst, int tid) const {
+    st(dst, tid, 0, r0);
+    if constexpr (UPT > 1) st(dst, tid, 1, r1);
+    if constexpr (UPT > 2) st(dst, tid, 2, r2);
+    if constexpr (UPT > 3) st(dst, tid, 3, r3);
+  }
+};
+
 // waves per SIMD the register allocation must leave room for: 3 / 2 / 1 workgroups per CU (C = 32 / 64 / 128; LDS allows no more)
 // IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
 template <int C, bool IOB>
-__global__ __launch_bounds__(RB_THREADS, (C == 128 ? 2 : 4)) void resblock_step_kernel(const TtsResblockDesc d) {
+// (measured: the 80-VGPR cap of C = 32 spills a little but 3 workgroups per CU beat 2 without spills: 14.5 vs 17.3 ms per step)
+__global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void resblock_step_kernel(const TtsResblockDesc d) {
   constexpr int KC = C;                   // channels per weight slab = all of them: one step per tap, act1(x) staged once
   constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
   constexpr int TP = C + 8;               // t1 pitch
@@ -57,27 +87,17 @@ __global__ __launch_bounds__(RB_THREADS, (C == 128 ? 2 : 4)) void resblock_step_
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
   const int steps1 = NCH * d.taps, total_steps = 2 * steps1;
 
-  uint4 wreg[UPT];
-  auto load_slab = [&](int step) {
+  RbSlab<UNITS, UPT> wreg;
+  // weight slab of step `step`: conv1 steps first, then conv2 (global layout [tap][C/8][C][8], one slab = one tap here)
+  auto slab_src = [&](int step) __attribute__((always_inline)) {
     const bool second = step >= steps1;
-    const int s = second ? step - steps1 : step;
-    const int chunk = s / d.taps, tap = s % d.taps;
+    const int sidx = second ? step - steps1 : step;
+    const int chunk = sidx / d.taps, tap = sidx % d.taps;
     const unsigned short* W = reinterpret_cast<const unsigned short*>(second ? d.w2 : d.w1);
-    const unsigned short* src = W + ((size_t)tap * (C / 8) + chunk * (KC / 8)) * C * 8;  // [tap][C/8][C][8]
-#pragma unroll
-    for (int q = 0; q < UPT; ++q) {
-      int u = tid + q * RB_THREADS;
-      u = u < UNITS ? u : UNITS - 1;  // unconditional load (idle threads re-read the last unit): no branch, no early wait
-      wreg[q] = *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
-    }
+    return W + ((size_t)tap * (C / 8) + chunk * (KC / 8)) * C * 8;
   };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < UPT; ++q) {
-      const int u = tid + q * RB_THREADS;
-      if (u < UNITS) *reinterpret_cast<uint4*>(ws + (size_t)buf * SLAB + (size_t)u * 8) = wreg[q];
-    }
-  };
+#define load_slab(step_) wreg.load(slab_src(step_), tid)
+#define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * SLAB, tid)
   load_slab(0);
   store_slab(0);
 
@@ -143,16 +163,15 @@ __global__ __launch_bounds__(RB_THREADS, (C == 128 ? 2 : 4)) void resblock_step_
           e = e < total ? e : total - 1;
           const int wr = e / Q8, c8 = (e % Q8) * 8;
           const unsigned int w4[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
-          uint4 o;
-          unsigned int* op = &o.x;
+          unsigned int o4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float lo = rb_bf2f(w4[q] & 0xFFFF), hi2 = rb_bf2f(w4[q] >> 16);
             lo = lo > 0.f ? lo : lo * d.slope;
             hi2 = hi2 > 0.f ? hi2 : hi2 * d.slope;
-            op[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
+            o4[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
           }
-          *reinterpret_cast<uint4*>(xa + wr * XP + c8) = o;
+          *reinterpret_cast<uint4*>(xa + wr * XP + c8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
         }
       }
     } else {
@@ -306,15 +325,14 @@ __global__ __launch_bounds__(RB_THREADS, (C == 128 ? 2 : 4)) void resblock_step_
       const float4 o0 = *reinterpret_cast<const float4*>(ot + orow * C + c8), o1 = *reinterpret_cast<const float4*>(ot + orow * C + c8 + 4);
       const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
       const unsigned int xw[4] = {xr.x, xr.y, xr.z, xr.w}, yw[4] = {yr.x, yr.y, yr.z, yr.w};
-      uint4 out;
-      unsigned int* op = &out.x;
+      unsigned int o4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float lo = ov[2 * q] + d.res_scale * rb_bf2f(xw[q] & 0xFFFF), hi2 = ov[2 * q + 1] + d.res_scale * rb_bf2f(xw[q] >> 16);
         if (d.accumulate) { lo += rb_bf2f(yw[q] & 0xFFFF); hi2 += rb_bf2f(yw[q] >> 16); }
-        op[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
+        o4[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
       }
-      *reinterpret_cast<uint4*>(yh + (size_t)row * d.ldy + c8) = out;
+      *reinterpret_cast<uint4*>(yh + (size_t)row * d.ldy + c8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
     return;
   }
@@ -335,6 +353,9 @@ __global__ __launch_bounds__(RB_THREADS, (C == 128 ? 2 : 4)) void resblock_step_
     }
   }
 }
+
+#undef load_slab
+#undef store_slab
 
 template <int C, bool IOB>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
