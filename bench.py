@@ -66,6 +66,19 @@ def cpu_baseline(phones, frames_per_phone, vocoder):
                 e2e_rtf=(ta + tv) / (w.numel() / 24000.0))
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_resblock_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if not collected."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_resblock_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = [r for r in json.load(f)["launches"] if r["kernel"] == kernel and r["act"] == "snake"]
+    if not rows:
+        return None
+    return sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -80,7 +93,8 @@ def main():
     ap.add_argument("--phones", type=int, default=128)
     ap.add_argument("--frames-per-phone", type=int, default=5)
     ap.add_argument("--vocoder", default="bigvgan", choices=["bigvgan", "hifigan"])
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
+                    help="bf16 = BASELINE.json configs[2] (bf16 MFMA GEMMs, fp32 statistics); fp32 = exact-parity configuration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
     args = ap.parse_args()
@@ -184,7 +198,7 @@ def main():
             "vocoder_rtf": t_voc / (args.steps * audio_s),
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),
             "roofline": {"bound": "mfma", "kernel": dominant, "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / peak, "traffic": None, "avg_launch_us": dom["avg_us"],
+                         "frac": dom["tflops"] / peak, "traffic": pmc_traffic(dominant), "avg_launch_us": dom["avg_us"],
                          "launches_per_step": dom["launches"] / args.steps, "flops_per_launch": dom["flops_per_launch"],
                          "share_of_step": dom["total_ms"] / (1e3 * elapsed)},
             "kernel_classes_warmup_step": {k: {"ms": round(v["total_ms"], 3), "launches": v["launches"], "tflops": round(v["tflops"], 2)}

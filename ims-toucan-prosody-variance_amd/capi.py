@@ -73,7 +73,8 @@ PROTOTYPES = {
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     "tts_l2_normalize": (C.c_int, [_p, _p, _i, _i, _p]),
-    "tts_groupnorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _i, _p]),
+    "tts_groupnorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _i, _i, _p, _p]),
+    "tts_groupnorm_workspace_floats": (C.c_int64, [_i, _i, _i]),
     "tts_relpos_attention": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "tts_dwconv_swish": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _p]),
     "tts_duration_from_log": (C.c_int, [_p, _p, _i, _p]),

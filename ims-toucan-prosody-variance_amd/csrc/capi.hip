@@ -24,7 +24,8 @@ int layernorm(const float*, int, float*, int, const float*, const float*, int, i
 int cond_layernorm(const float*, int, float*, int, const float*, const float*, int, const TtsTile*, int, int, hipStream_t);
 int l2_normalize(const float*, float*, int, int, hipStream_t);
 int groupnorm(const float*, int, float*, int, const float*, const float*, int, int, float, int, const float*, int, const int*,
-              const int*, int, hipStream_t);
+              const int*, int, int, float*, hipStream_t);
+long groupnorm_workspace_floats(int, int, int);
 int axpby(const float*, int, float, const float*, int, float, float*, int, int, int, hipStream_t);
 int relpos_attention(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
                      int, hipStream_t);
@@ -85,8 +86,13 @@ int tts_l2_normalize(const float* x, float* y, int32_t rows, int32_t c, tts_stre
 
 int tts_groupnorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta, int32_t c, int32_t groups,
                   float eps, int32_t apply_tanh, const float* res, int32_t ld_res, const int32_t* seq_begin, const int32_t* seq_end,
-                  int32_t n_seq, tts_stream_t stream) {
-  return tts::groupnorm(x, ldx, y, ldy, gamma, beta, c, groups, eps, apply_tanh, res, ld_res, seq_begin, seq_end, n_seq, ST(stream));
+                  int32_t n_seq, int32_t max_len, float* workspace, tts_stream_t stream) {
+  return tts::groupnorm(x, ldx, y, ldy, gamma, beta, c, groups, eps, apply_tanh, res, ld_res, seq_begin, seq_end, n_seq, max_len, workspace,
+                        ST(stream));
+}
+
+int64_t tts_groupnorm_workspace_floats(int32_t n_seq, int32_t max_len, int32_t groups) {
+  return tts::groupnorm_workspace_floats(n_seq, max_len, groups);
 }
 
 int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u, const float* bias_v,

@@ -94,52 +94,71 @@ __global__ __launch_bounds__(64) void l2norm_kernel(const float* __restrict__ x,
 
 // GroupNorm over (c/groups channels) x (all frames of ONE utterance) + affine + optional tanh + optional residual.
 // Layers/PostNet.py:44-56 (GroupNorm(32,256) x4 with Tanh, GroupNorm(20,80) last), eps 1e-5.
-// One workgroup per utterance; thread = channel (c <= 256).  Three sweeps over the utterance's frames
-// (sum -> centred sum of squares -> apply); every sweep reads whole rows, i.e. contiguous c*4-byte segments.
 // The statistics are a time-axis reduction, so they MUST be per utterance (padding may never leak in).
-__global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int c,
-                                                        int groups, float eps, int apply_tanh, const float* __restrict__ res,
-                                                        int ld_res, const int* __restrict__ seq_begin, const int* __restrict__ seq_end) {
-  __shared__ float red[256];
-  const int u = blockIdx.x;
-  const int r0 = seq_begin[u], r1 = seq_end[u];
-  const int ch = threadIdx.x;
-  const int cpg = c / groups;
-  const bool on = ch < c;
-  const float cnt = (float)cpg * (float)(r1 - r0);
-  // pass 1: mean
-  float s = 0.f;
-  if (on)
-    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + ch];
-  red[ch] = s;
-  __syncthreads();
-  float gsum = 0.f;
-  if (on) {
-    const int g0 = (ch / cpg) * cpg;
-    for (int k = 0; k < cpg; ++k) gsum += red[g0 + k];
-  }
-  const float mean = gsum / cnt;
-  __syncthreads();
-  // pass 2: centred second moment
-  float q = 0.f;
-  if (on)
+// Two launches over a (64-frame chunk, utterance) grid, thread = channel (c <= 256, whole rows = contiguous segments):
+//   1. partial (sum, sum of squares) per (utterance, chunk, group) into a workspace - no atomics, so the result is
+//      bit-reproducible from run to run and across ranks;
+//   2. every workgroup adds the partials of its utterance in chunk order (fp64), then normalises its own 64 frames.
+constexpr int GN_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __restrict__ x, int ldx, int c, int groups,
+                                                                const int* __restrict__ seq_begin, const int* __restrict__ seq_end,
+                                                                float* __restrict__ ws, int n_chunks) {
+  __shared__ float rs[256], rq[256];
+  const int u = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = seq_begin[u] + chunk * GN_CHUNK;
+  const int r1 = min(seq_end[u], r0 + GN_CHUNK);
+  const int ch = threadIdx.x, cpg = c / groups;
+  float s = 0.f, q = 0.f;
+  if (ch < c)
     for (int r = r0; r < r1; ++r) {
-      const float dlt = x[(size_t)r * ldx + ch] - mean;
-      q += dlt * dlt;
+      const float v = x[(size_t)r * ldx + ch];
+      s += v;
+      q = fmaf(v, v, q);
     }
-  red[ch] = q;
+  rs[ch] = s;
+  rq[ch] = q;
   __syncthreads();
-  float gq = 0.f;
-  if (on) {
-    const int g0 = (ch / cpg) * cpg;
-    for (int k = 0; k < cpg; ++k) gq += red[g0 + k];
+  if (ch < groups) {
+    float gs = 0.f, gq = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      gs += rs[ch * cpg + k];
+      gq += rq[ch * cpg + k];
+    }
+    float* w = ws + (((size_t)u * n_chunks + chunk) * groups + ch) * 2;
+    w[0] = gs;
+    w[1] = gq;
   }
-  if (!on) return;
-  const float rstd = 1.0f / sqrtf(gq / cnt + eps);
-  const float ga = gamma[ch] * rstd, be = beta[ch] - mean * gamma[ch] * rstd;
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int c,
+                                                              int groups, float eps, int apply_tanh, const float* __restrict__ res,
+                                                              int ld_res, const int* __restrict__ seq_begin, const int* __restrict__ seq_end,
+                                                              const float* __restrict__ ws, int n_chunks) {
+  const int u = blockIdx.y, chunk = blockIdx.x;
+  const int sb = seq_begin[u], se = seq_end[u];
+  const int r0 = sb + chunk * GN_CHUNK;
+  if (r0 >= se) return;
+  const int r1 = min(se, r0 + GN_CHUNK);
+  const int ch = threadIdx.x;
+  if (ch >= c) return;
+  const int cpg = c / groups, g = ch / cpg;
+  const int used = (se - sb + GN_CHUNK - 1) / GN_CHUNK;  // chunks that hold frames of this utterance
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < used; ++k) {
+    const float* w = ws + (((size_t)u * n_chunks + k) * groups + g) * 2;
+    s += (double)w[0];
+    q += (double)w[1];
+  }
+  const double cnt = (double)cpg * (double)(se - sb);
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float ga = gamma[ch] * rstd, be = beta[ch] - (float)mean * ga;
   for (int r = r0; r < r1; ++r) {
-    float v = x[(size_t)r * ldx + ch] * ga + be;
+    float v = fmaf(x[(size_t)r * ldx + ch], ga, be);
     if (apply_tanh) v = tanhf(v);
     if (res) v += res[(size_t)r * ld_res + ch];
     y[(size_t)r * ldy + ch] = v;
@@ -192,11 +211,21 @@ int l2_normalize(const float* x, float* y, int rows, int c, hipStream_t st) {
 }
 
 int groupnorm(const float* x, int ldx, float* y, int ldy, const float* g, const float* b, int c, int groups, float eps,
-              int apply_tanh, const float* res, int ld_res, const int* sb, const int* se, int n_seq, hipStream_t st) {
+              int apply_tanh, const float* res, int ld_res, const int* sb, const int* se, int n_seq, int max_len, float* ws,
+              hipStream_t st) {
   TTS_CHECK_ARG(c > 0 && c <= 256 && groups > 0 && c % groups == 0, "groupnorm: c=%d groups=%d unsupported", c, groups);
-  if (n_seq == 0) return TTS_OK;
-  hipLaunchKernelGGL(groupnorm_kernel, dim3(n_seq), dim3(256), 0, st, x, ldx, y, ldy, g, b, c, groups, eps, apply_tanh, res, ld_res, sb, se);
+  TTS_CHECK_ARG(ws != nullptr, "groupnorm: workspace of tts_groupnorm_workspace_floats() floats required");
+  if (n_seq == 0 || max_len == 0) return TTS_OK;
+  const int n_chunks = (max_len + GN_CHUNK - 1) / GN_CHUNK;
+  dim3 grid(n_chunks, n_seq);
+  hipLaunchKernelGGL(groupnorm_partial_kernel, grid, dim3(256), 0, st, x, ldx, c, groups, sb, se, ws, n_chunks);
+  hipLaunchKernelGGL(groupnorm_apply_kernel, grid, dim3(256), 0, st, x, ldx, y, ldy, g, b, c, groups, eps, apply_tanh, res, ld_res, sb, se,
+                     ws, n_chunks);
   return launch_status("groupnorm");
+}
+
+long groupnorm_workspace_floats(int n_seq, int max_len, int groups) {
+  return (long)n_seq * ((max_len + GN_CHUNK - 1) / GN_CHUNK) * groups * 2;
 }
 
 int axpby(const float* x, int ldx, float a, const float* z, int ldz, float b, float* y, int ldy, int rows, int c, hipStream_t st) {

@@ -138,9 +138,10 @@ class Ops:
 
     def groupnorm(self, x, y, gamma, beta, c, groups, rag, tanh, res=None, eps=1e-5):
         sb, se = rag.bounds()
+        ws = self.empty(max(1, int(self.lib.tts_groupnorm_workspace_floats(rag.n_seq, rag.max_len, groups))))
         capi.check(self.lib.tts_groupnorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), gamma.data_ptr(), beta.data_ptr(), c, groups, eps,
-                                          1 if tanh else 0, _ptr(res), _ld(res), sb.data_ptr(), se.data_ptr(), rag.n_seq, self.stream()),
-                   "tts_groupnorm")
+                                          1 if tanh else 0, _ptr(res), _ld(res), sb.data_ptr(), se.data_ptr(), rag.n_seq, rag.max_len,
+                                          ws.data_ptr(), self.stream()), "tts_groupnorm")
         return y
 
     def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag, tile_rows=128):

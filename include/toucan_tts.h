@@ -131,11 +131,14 @@ int tts_cond_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const
 /* Row-wise L2 normalisation (torch.nn.functional.normalize, eps 1e-12). InferenceToucanTTS.py:202, Conformer.py:132. */
 int tts_l2_normalize(const float* x, float* y, int32_t rows, int32_t c, tts_stream_t stream);
 
-/* GroupNorm over (c/groups channels x all frames of one utterance) + optional tanh; one launch for the
- * whole batch. Layers/PostNet.py:44-56. seq_begin/seq_end are device arrays [n_seq]. */
+/* GroupNorm over (c/groups channels x all frames of one utterance) + optional tanh + optional residual; two launches
+ * (deterministic partial sums, then apply) for the whole batch. Layers/PostNet.py:44-56.  seq_begin/seq_end are device
+ * arrays [n_seq]; max_len = longest utterance; workspace: tts_groupnorm_workspace_floats(n_seq, max_len, groups) floats. */
 int tts_groupnorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta,
                   int32_t c, int32_t groups, float eps, int32_t apply_tanh, const float* res, int32_t ld_res,
-                  const int32_t* seq_begin, const int32_t* seq_end, int32_t n_seq, tts_stream_t stream);
+                  const int32_t* seq_begin, const int32_t* seq_end, int32_t n_seq, int32_t max_len, float* workspace,
+                  tts_stream_t stream);
+int64_t tts_groupnorm_workspace_floats(int32_t n_seq, int32_t max_len, int32_t groups);
 
 /* Relative-position multi-head self-attention, flash style (scores never reach HBM):
  *   s[i,j] = ((q_i+u_h).k_j + (q_i+v_h).P[i-j]) / sqrt(dk); softmax over the utterance's keys; ctx = s.v

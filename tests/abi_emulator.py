@@ -243,7 +243,11 @@ class Emulator:
         _mat(y, rows, c, c)[:] = (X / n).astype(np.float32)
         return 0
 
-    def tts_groupnorm(self, x, ldx, y, ldy, gamma, beta, c, groups, eps, apply_tanh, res, ld_res, seq_begin, seq_end, n_seq, stream):
+    def tts_groupnorm_workspace_floats(self, n_seq, max_len, groups):
+        return n_seq * ((max_len + 63) // 64) * groups * 2
+
+    def tts_groupnorm(self, x, ldx, y, ldy, gamma, beta, c, groups, eps, apply_tanh, res, ld_res, seq_begin, seq_end, n_seq, max_len,
+                      workspace, stream):
         self._count("groupnorm")
         sb, se = _arr(seq_begin, n_seq, np.int32), _arr(seq_end, n_seq, np.int32)
         g, b = _arr(gamma, c).astype(np.float64), _arr(beta, c).astype(np.float64)
