@@ -365,7 +365,11 @@ static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   const size_t lds = (xs_elems + (size_t)2 * NH * BK * C::BN) * ESZ;
   TTS_CHECK_ARG(lds <= 160 * 1024, "conv1d: LDS %zu B exceeds 160 KiB (taps %d dil %d)", lds, d.taps, d.dil);
   auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static bool lds_raised = false;  // once per instantiation (also keeps the call out of stream captures)
+  if (lds > 64 * 1024 && !lds_raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_raised = true;
+  }
   hipLaunchKernelGGL(k, grid, block, lds, st, d);
   return launch_status("conv1d");
 }

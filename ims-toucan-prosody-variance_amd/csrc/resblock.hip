@@ -366,7 +366,11 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static bool lds_raised = false;  // once per instantiation (also keeps the call out of stream captures)
+  if (lds > 64 * 1024 && !lds_raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    lds_raised = true;
+  }
   hipLaunchKernelGGL(k, dim3(d.n_tiles), dim3(RB_THREADS), lds, st, d);
   return launch_status("resblock_step");
 }

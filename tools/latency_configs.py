@@ -1,0 +1,66 @@
+"""Latency / throughput of the other BASELINE.json configurations on one MI355X (run on the GPU box).
+
+  configs[1]: batch = 1, 128 phonemes, acoustic model fp32, mel only (no vocoder)
+  configs[0]-like: one ~20-phoneme utterance end to end with the Avocodo vocoder (fp32)
+Prints one JSON line per configuration (median of `--reps` after 3 warm-ups, host wall clock around a device sync)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import ims_toucan_prosody_variance_amd  # noqa: F401
+from ims_toucan_prosody_variance_amd import engine, fixture_weights as fw, synthetic as syn
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--graphs", action="store_true", help="replay the pass as HIP graphs (fixed shapes)")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, use_graphs=args.graphs)
+    voc = engine.VocoderEngine(fw.hifigan_state_dict(), "hifigan", dev, use_graphs=args.graphs)
+
+    L = 128
+    text = [torch.from_numpy(syn.utterance_features(0, L, word_boundaries=False)).to(dev)]
+    emb = torch.from_numpy(syn.utterance_embedding(0))[None].to(dev)
+    dur = [torch.full((L,), 5, dtype=torch.int32, device=dev)]
+    z = [torch.from_numpy(syn.postflow_noise(0, 5 * L)).to(dev)]
+    t = timeit(lambda: ac.forward(text, emb, [syn.LANG_EN], durations=dur, z_noise=z), args.reps)
+    print(json.dumps({"config": "configs[1]: batch=1 x 128 phonemes, acoustic fp32, mel only", "graphs": args.graphs, "ms": 1e3 * t,
+                      "mel_frames_per_s": 5 * L / t}))
+
+    L = 20
+    text = [torch.from_numpy(syn.utterance_features(1, L)).to(dev)]
+    emb = torch.from_numpy(syn.utterance_embedding(1))[None].to(dev)
+
+    def e2e():
+        out = ac.forward(text, emb, [syn.LANG_EN])
+        return voc.forward(out["mel_packed"], out["rag_mel"])
+
+    t = timeit(e2e, args.reps)
+    wav, _ = e2e()
+    print(json.dumps({"config": "configs[0]-like: one 20-phoneme utterance, predicted durations, acoustic + Avocodo fp32, end to end",
+                      "graphs": args.graphs, "ms": 1e3 * t, "audio_s": wav.numel() / 24000.0, "rtf": t / (wav.numel() / 24000.0)}))
+
+
+if __name__ == "__main__":
+    main()
