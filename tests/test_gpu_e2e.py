@@ -193,6 +193,29 @@ def test_hip_graph_replay_is_bit_identical_to_eager():
     _check_mel(out["mel"][0], g, "graph replay")
 
 
+def test_drop_in_interface_on_the_gpu(tmp_path, monkeypatch):
+    """The reference's entry point (import path, ctor keywords, read_to_file) end to end on cuda with reference-format checkpoints."""
+    import wave
+    from ims_toucan_prosody_variance_amd import interface
+    models = tmp_path / "Models"
+    interface.write_fixture_checkpoints(str(models), n_lang=20)
+    monkeypatch.setattr(interface, "MODELS_DIR", str(models))
+    from InferenceInterfaces.ToucanTTSInterface import ToucanTTSInterface
+    for faster in (True, False):
+        tts = ToucanTTSInterface(device="cuda", tts_model_path="Meta", faster_vocoder=faster)
+        tts.set_language("en")
+        wav = tts("~həlˈoʊ wˈɜːld~#", input_is_phones=True)
+        assert wav.is_cuda and wav.dim() == 1 and torch.isfinite(wav).all() and float(wav.abs().max()) <= 1.0
+        frames = int(tts.last_durations[0].sum())
+        assert wav.numel() == 384 * (frames - frames % 2)
+        out = tmp_path / f"x{int(faster)}.wav"
+        tts.read_to_file(["~həlˈoʊ~#", "", "~wˈɜːld~#"], str(out), silent=True, input_is_phones=True)
+        with wave.open(str(out)) as f:
+            assert f.getframerate() == 24000 and f.getnframes() > 3 * 10600
+        both = tts.synthesize_batch(["~həlˈoʊ~#", "~wˈɜːld tˈu~#"])
+        assert len(both) == 2 and all(w.is_cuda for w in both)
+
+
 def test_native_library_is_the_one_loaded():
     from ims_toucan_prosody_variance_amd import capi
     import ctypes
