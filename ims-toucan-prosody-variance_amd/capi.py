@@ -59,7 +59,6 @@ class TtsResblockDesc(C.Structure):
     ]
 
 
-RESBLOCK_TILE_ROWS = 224
 IO_X_BF16, IO_Y_BF16, IO_RES_BF16 = 1, 2, 4
 
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
@@ -70,6 +69,7 @@ PROTOTYPES = {
     "tts_conv1d_n_tile": (C.c_int, [_i, _i]),
     "tts_conv1d": (C.c_int, [C.POINTER(TtsConvDesc), _p]),
     "tts_resblock_step": (C.c_int, [C.POINTER(TtsResblockDesc), _p]),
+    "tts_resblock_tile_rows": (C.c_int, [_i]),
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     "tts_l2_normalize": (C.c_int, [_p, _p, _i, _i, _p]),

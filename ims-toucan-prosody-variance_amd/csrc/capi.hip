@@ -41,6 +41,7 @@ int snake_aa(const float*, int, float*, int, const float*, const float*, const f
 int conv_post(const float*, int, int, const float*, float, int, float, float*, const TtsTile*, int, int, int, hipStream_t);
 int gather_rows(const float*, int, const int*, float*, int, int, int, hipStream_t);
 int resblock_step(const TtsResblockDesc& d, hipStream_t st);
+int resblock_tile_rows(int c);
 
 }  // namespace tts
 
@@ -61,6 +62,8 @@ int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream) {
   }
   return tts::conv1d_dispatch(*d, ST(stream));
 }
+
+int tts_resblock_tile_rows(int32_t c) { return tts::resblock_tile_rows(c); }
 
 int tts_resblock_step(const TtsResblockDesc* d, tts_stream_t stream) {
   if (!d) {

@@ -25,21 +25,30 @@ namespace tts {
 __device__ __forceinline__ unsigned short rb_f2bf(float f) { return f32_to_bf16(f); }
 __device__ __forceinline__ float rb_bf2f(unsigned short u) { return bf16_to_f32(u); }
 
-constexpr int RB_BM = 224, RB_M1 = 256, RB_LEAD = 16, RB_THREADS = 512;
+constexpr int RB_LEAD = 16;
+// C <= 128: conv1 on M1 = 256 rows (8 waves), 224 output rows, whole-C weight slabs.
+// C == 256: conv1 on M1 = 128 rows (4 waves, 8 accumulators each), 96 output rows, 64-channel slabs (LDS: t1 alone is 66 KB).
+template <int C>
+struct RbCfg {
+  static constexpr int M1 = C == 256 ? 128 : 256;
+  static constexpr int BM = M1 - 2 * RB_LEAD;
+  static constexpr int THREADS = 2 * M1;
+  static constexpr int KC = C == 256 ? 64 : C;
+};
 
 // register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
 // unconditional (clamped) loads, so the prefetch is not fenced by a branch
-template <int UNITS, int UPT>
+template <int UNITS, int UPT, int THREADS>
 struct RbSlab {
-  static_assert(UPT >= 1 && UPT <= 4, "slab register staging holds at most 4 units per thread");
-  uint4 r0, r1, r2, r3;
+  static_assert(UPT >= 1 && UPT <= 8, "slab register staging holds at most 8 units per thread");
+  uint4 r0, r1, r2, r3, r4, r5, r6, r7;
   static __device__ __forceinline__ uint4 ld(const unsigned short* __restrict__ src, int tid, int q) {
-    int u = tid + q * 512;
+    int u = tid + q * THREADS;
     u = u < UNITS ? u : UNITS - 1;
     return *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
   }
   static __device__ __forceinline__ void st(unsigned short* dst, int tid, int q, const uint4& v) {
-    const int u = tid + q * 512;
+    const int u = tid + q * THREADS;
     if (u < UNITS) *reinterpret_cast<uint4*>(dst + (size_t)u * 8) = v;
   }
   __device__ __forceinline__ void load(const unsigned short* __restrict__ src, int tid) {
@@ -47,12 +56,20 @@ struct RbSlab {
     if constexpr (UPT > 1) r1 = ld(src, tid, 1);
     if constexpr (UPT > 2) r2 = ld(src, tid, 2);
     if constexpr (UPT > 3) r3 = ld(src, tid, 3);
+    if constexpr (UPT > 4) r4 = ld(src, tid, 4);
+    if constexpr (UPT > 5) r5 = ld(src, tid, 5);
+    if constexpr (UPT > 6) r6 = ld(src, tid, 6);
+    if constexpr (UPT > 7) r7 = ld(src, tid, 7);
   }
   __device__ __forceinline__ void store(unsigned short* dst, int tid) const {
     st(dst, tid, 0, r0);
     if constexpr (UPT > 1) st(dst, tid, 1, r1);
     if constexpr (UPT > 2) st(dst, tid, 2, r2);
     if constexpr (UPT > 3) st(dst, tid, 3, r3);
+    if constexpr (UPT > 4) st(dst, tid, 4, r4);
+    if constexpr (UPT > 5) st(dst, tid, 5, r5);
+    if constexpr (UPT > 6) st(dst, tid, 6, r6);
+    if constexpr (UPT > 7) st(dst, tid, 7, r7);
   }
 };
 
@@ -60,8 +77,9 @@ struct RbSlab {
 // IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
 template <int C, bool IOB>
 // (measured: the 80-VGPR cap of C = 32 spills a little but 3 workgroups per CU beat 2 without spills: 14.5 vs 17.3 ms per step)
-__global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void resblock_step_kernel(const TtsResblockDesc d) {
-  constexpr int KC = C;                   // channels per weight slab = all of them: one step per tap, act1(x) staged once
+__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? 6 : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d) {
+  constexpr int RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
+  constexpr int KC = RbCfg<C>::KC;        // channels per weight slab (all of them for C <= 128: one step per tap, act1(x) staged once)
   constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
   constexpr int TP = C + 8;               // t1 pitch
   constexpr int TN = C / 32;              // 32-column accumulators per wave
@@ -87,7 +105,7 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
   const int steps1 = NCH * d.taps, total_steps = 2 * steps1;
 
-  RbSlab<UNITS, UPT> wreg;
+  RbSlab<UNITS, UPT, RB_THREADS> wreg;
   // weight slab of step `step`: conv1 steps first, then conv2 (global layout [tap][C/8][C][8], one slab = one tap here)
   auto slab_src = [&](int step) __attribute__((always_inline)) {
     const bool second = step >= steps1;
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
     const int wbase = l0 - RB_LEAD - h1;
     if (snake) {
       // anti-aliased snake while staging: item = (8*NCH1 window rows, channel), streamed so that only the first chunk pays the halo
-      constexpr int NCH1 = C == 32 ? 3 : 5, GR = 8 * NCH1;
+      constexpr int NCH1 = (C == 32 || C == 256) ? 3 : 5, GR = 8 * NCH1;
       const int items = ((win_rows + GR - 1) / GR) * KC;
       for (int it = tid; it < items; it += RB_THREADS) {
         const int chl = it % KC, wr0 = (it / KC) * GR;
@@ -241,37 +259,55 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
   }
   __syncthreads();
   if (snake) {
-    // second anti-aliased snake, in place on t1: every thread first computes all its outputs into registers, then overwrites.
-    // item = (8*NCH2 rows, channel): 256 rows x C channels over 512 threads = C/2 values per thread
-    constexpr int NCH2 = C == 32 ? 2 : 4, GR = 8 * NCH2;
-    constexpr int ITEMS = (RB_M1 / GR) * C / RB_THREADS;
-    static_assert((RB_M1 / GR) * C % RB_THREADS == 0, "in-place snake items must tile the workgroup");
-    float o[ITEMS][GR];
     const int base = l0 - RB_LEAD;  // local frame of t1 row 0
-#pragma unroll
-    for (int q = 0; q < ITEMS; ++q) {
-      const int it = tid + q * RB_THREADS;
-      const int chn = it % C, i0 = (it / C) * GR;
-      const int t0 = base + i0;
-      const bool live = t0 + GR - 1 >= 0 && t0 < T;
-#pragma unroll
-      for (int i = 0; i < GR; ++i) o[q][i] = 0.0f;
-      if (live) {
-        snake_stream<NCH2>([&](int q2) {
+    if constexpr (C == RB_THREADS) {
+      // C = 256: one thread per channel streams down all M1 rows.  The stream reads every raw row (up to 13 rows ahead)
+      // into registers before it overwrites it, and no other thread touches this channel: in place without a barrier.
+      const int chn = tid;
+      const int t0 = base;
+      if (t0 + RB_M1 - 1 >= 0 && t0 < T) {
+        snake_stream<RB_M1 / 8>([&](int q2) {
           int i = q2 - base;
-          i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);  // only reached by rows whose outputs are not consumed
+          i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);
           return rb_bf2f(t1[i * TP + chn]);
-        }, [&](int i, float v) { o[q][i] = (t0 + i >= 0 && t0 + i < T) ? v : 0.0f; }, T, t0, f, expf(d.alpha2[chn]),
-                           1.0f / (expf(d.beta2[chn]) + 1e-9f));
+        }, [&](int i, float v) { t1[i * TP + chn] = rb_f2bf((t0 + i >= 0 && t0 + i < T) ? v : 0.0f); }, T, t0, f, expf(d.alpha2[chn]),
+                                1.0f / (expf(d.beta2[chn]) + 1e-9f));
+      } else {
+        for (int i = 0; i < RB_M1; ++i) t1[i * TP + chn] = 0;
       }
-    }
-    __syncthreads();
+      __syncthreads();
+    } else {
+      // in place on t1: every thread first computes all its outputs into registers, then overwrites.
+      // item = (8*NCH2 rows, channel): 256 rows x C channels over 512 threads = C/2 values per thread
+      constexpr int NCH2 = C == 32 ? 2 : 4, GR = 8 * NCH2;
+      constexpr int ITEMS = (RB_M1 / GR) * C / RB_THREADS;
+      static_assert((RB_M1 / GR) * C % RB_THREADS == 0, "in-place snake items must tile the workgroup");
+      float o[ITEMS][GR];
 #pragma unroll
-    for (int q = 0; q < ITEMS; ++q) {
-      const int it = tid + q * RB_THREADS;
-      const int chn = it % C, i0 = (it / C) * GR;
+      for (int q = 0; q < ITEMS; ++q) {
+        const int it = tid + q * RB_THREADS;
+        const int chn = it % C, i0 = (it / C) * GR;
+        const int t0 = base + i0;
+        const bool live = t0 + GR - 1 >= 0 && t0 < T;
 #pragma unroll
-      for (int i = 0; i < GR; ++i) t1[(i0 + i) * TP + chn] = rb_f2bf(o[q][i]);
+        for (int i = 0; i < GR; ++i) o[q][i] = 0.0f;
+        if (live) {
+          snake_stream<NCH2>([&](int q2) {
+            int i = q2 - base;
+            i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);  // only reached by rows whose outputs are not consumed
+            return rb_bf2f(t1[i * TP + chn]);
+          }, [&](int i, float v) { o[q][i] = (t0 + i >= 0 && t0 + i < T) ? v : 0.0f; }, T, t0, f, expf(d.alpha2[chn]),
+                             1.0f / (expf(d.beta2[chn]) + 1e-9f));
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < ITEMS; ++q) {
+        const int it = tid + q * RB_THREADS;
+        const int chn = it % C, i0 = (it / C) * GR;
+#pragma unroll
+        for (int i = 0; i < GR; ++i) t1[(i0 + i) * TP + chn] = rb_f2bf(o[q][i]);
+      }
     }
   }
 
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(RB_THREADS, (C == 32 ? 6 : (C == 64 ? 4 : 2))) void
 
 template <int C, bool IOB>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
-  constexpr int KC = C;
+  constexpr int KC = RbCfg<C>::KC, RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   const int h1 = (d.taps - 1) / 2 * d.dil;
   const size_t xa = (((size_t)(RB_M1 + 2 * h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
   size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * KC * C) * 2;
@@ -375,12 +411,15 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   return launch_status("resblock_step");
 }
 
+int resblock_tile_rows(int c) { return c == 256 ? RbCfg<256>::BM : RbCfg<32>::BM; }
+
 int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.x && d.y && d.w1 && d.w2 && d.b1 && d.b2 && d.tiles, "resblock_step: null pointer");
-  TTS_CHECK_ARG(d.c == 32 || d.c == 64 || d.c == 128, "resblock_step: C=%d unsupported (32, 64, 128)", d.c);
+  TTS_CHECK_ARG(d.c == 32 || d.c == 64 || d.c == 128 || d.c == 256, "resblock_step: C=%d unsupported (32, 64, 128, 256)", d.c);
   TTS_CHECK_ARG(d.taps >= 1 && d.taps <= 11 && (d.taps & 1) && d.dil >= 1, "resblock_step: taps %d / dil %d unsupported", d.taps, d.dil);
   TTS_CHECK_ARG((d.taps - 1) / 2 + 6 <= RB_LEAD, "resblock_step: conv2 halo too large");
-  TTS_CHECK_ARG(d.tile_rows == RB_BM, "resblock_step: tile table must use %d rows, got %d", RB_BM, d.tile_rows);
+  const int bm = resblock_tile_rows(d.c);
+  TTS_CHECK_ARG(d.tile_rows == bm, "resblock_step: tile table must use %d rows for C=%d, got %d", bm, d.c, d.tile_rows);
   TTS_CHECK_ARG(d.act == TTS_PRE_LRELU || d.act == TTS_PRE_SNAKE, "resblock_step: act must be LRELU or SNAKE");
   TTS_CHECK_ARG(d.act != TTS_PRE_SNAKE || (d.alpha1 && d.beta1 && d.alpha2 && d.beta2 && d.filt), "resblock_step: snake parameters missing");
   TTS_CHECK_ARG((d.ldx & 3) == 0 && ((uintptr_t)d.x & 15) == 0, "resblock_step: x must be 16-byte aligned rows");
@@ -390,13 +429,15 @@ int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
     switch (d.c) {
       case 32: return launch_rb<32, true>(d, st);
       case 64: return launch_rb<64, true>(d, st);
-      default: return launch_rb<128, true>(d, st);
+      case 128: return launch_rb<128, true>(d, st);
+      default: return launch_rb<256, true>(d, st);
     }
   }
   switch (d.c) {
     case 32: return launch_rb<32, false>(d, st);
     case 64: return launch_rb<64, false>(d, st);
-    default: return launch_rb<128, false>(d, st);
+    case 128: return launch_rb<128, false>(d, st);
+    default: return launch_rb<256, false>(d, st);
   }
 }
 

@@ -95,7 +95,8 @@ class Ops:
     def resblock_step(self, c1, c2, x, y, rag, act, slope=0.1, snake1=None, snake2=None, filt=None, alpha=1.0, res_scale=1.0,
                       accumulate=False):
         """Fused residual step (tts_resblock_step): y = alpha*conv2(act(conv1(act(x)))) + res_scale*x (+ y)."""
-        tiles, n_tiles = rag.tiles(capi.RESBLOCK_TILE_ROWS)
+        tile_rows = self.lib.tts_resblock_tile_rows(c1.cin)
+        tiles, n_tiles = rag.tiles(tile_rows)
         d = capi.TtsResblockDesc()
         d.x, d.ldx, d.y, d.ldy = x.data_ptr(), _ld(x), y.data_ptr(), _ld(y)
         d.c, d.taps, d.dil = c1.cin, c1.taps, c1.dil
@@ -108,7 +109,7 @@ class Ops:
         d.alpha, d.res_scale, d.accumulate = alpha, res_scale, 1 if accumulate else 0
         assert _is_bf16(x) == _is_bf16(y)
         d.io_bf16 = 1 if _is_bf16(x) else 0
-        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, capi.RESBLOCK_TILE_ROWS
+        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
         if tm is not None and tm.wants_name("resblock_step<%d>" % c1.cin):
             ev0, ev1 = tm.events()
@@ -611,6 +612,9 @@ class VocoderEngine:
         self.fuse_snake = fuse_snake
         # bf16 only: one fused kernel per residual dilation step (tts_resblock_step) for the stages with C <= 128
         self.fuse_step = bf16 if fuse_step is None else (fuse_step and bf16)
+        # C = 256 (stage 1) is supported by the fused kernel too, but with one 4-wave workgroup per CU it only ties the
+        # unfused convs + stand-alone snakes (9.1 vs 9.0 ms per step measured), so stage 1 keeps the unfused path
+        self.fuse_max_channels = 128
         self.store_bf16 = self.fuse_step if store_bf16 is None else (store_bf16 and self.fuse_step)
         self.ops = Ops(device)
         self.device = self.ops.device
@@ -666,7 +670,7 @@ class VocoderEngine:
             ch //= 2
             # transposed conv as a 3-tap polyphase conv; [R, u*ch] re-viewed as [R*u, ch]
             # stages that run the fused residual step keep their residual stream as bf16 in HBM (bandwidth-bound kernels)
-            fused = self.fuse_step and ch <= 128
+            fused = self.fuse_step and ch <= self.fuse_max_channels
             sdt = torch.bfloat16 if (fused and self.store_bf16) else torch.float32
             y = ops.conv(self.ups[i], x, ops.empty(R, u * ch, dtype=sdt), rag, pre=PRE_NONE if big else PRE_LRELU, pre_slope=0.1, compute=cp)
             R, rag = R * u, rag.scaled(u)
@@ -680,7 +684,7 @@ class VocoderEngine:
                 for dd in range(3):
                     c1, c2 = self.blocks[i][j][dd]
                     last = dd == 2
-                    if self.fuse_step and ch <= 128:
+                    if fused:
                         # one launch per dilation step: act, conv(dil), act, conv(1), + x (and the stage mean on the last step)
                         sn1, sn2 = self.snakes[i][j][dd] if big else (None, None)
                         dst = stage_out if last else bufs[dd % 2]

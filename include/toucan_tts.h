@@ -101,7 +101,7 @@ int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream);
  * act = TTS_PRE_LRELU (slope) or TTS_PRE_SNAKE (anti-aliased SnakeBeta with (alpha1,beta1) / (alpha2,beta2), filter [12]).
  * Replaces one dilation step of BigVGAN/AMP.py:53-58 (a1, c1, a2, c2, + x) or Layers/ResidualBlock.py:93-97; with
  * alpha = res_scale = 1/3 and accumulate it also forms the stage mean of InferenceBigVGAN.py:82-88.
- * Weights: bf16 [taps][C/8][C][8] as produced for tts_conv1d(compute = 1).  The tile table must use 224 rows per tile.
+ * Weights: bf16 [taps][C/8][C][8] as produced for tts_conv1d(compute = 1).  C in {32, 64, 128, 256}.
  */
 typedef struct {
   const float* x; int32_t ldx;
@@ -116,7 +116,8 @@ typedef struct {
   const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows;
 } TtsResblockDesc;
 
-#define TTS_RESBLOCK_TILE_ROWS 224
+/* rows per tile the fused step uses for C channels (224 for C <= 128, 96 for C = 256): build the tile table with it */
+int tts_resblock_tile_rows(int32_t c);
 int tts_resblock_step(const TtsResblockDesc* d, tts_stream_t stream);
 
 /* y[r,:] = LayerNorm(x[r,:]) * g + b over `c` channels, eps as given. Layers/LayerNorm.py:24-36 (eps 1e-12). */

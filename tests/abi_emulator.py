@@ -173,6 +173,9 @@ class Emulator:
             _store(d.y, sb, se, d.cout, d.ldy, v, d.io_flags & capi.IO_Y_BF16)
         return 0
 
+    def tts_resblock_tile_rows(self, c):
+        return self._reallib().tts_resblock_tile_rows(c)
+
     def tts_resblock_step(self, dref, stream):
         """bf16 rounding points as in csrc/resblock.hip: act1(x) -> bf16; conv1 (+b1) -> bf16 (LeakyReLU before the
         rounding, snake after it) -> act2 -> bf16; conv2; fp32 epilogue."""

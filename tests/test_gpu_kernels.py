@@ -114,7 +114,8 @@ def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compu
 
 
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 225]), (32, 11, 5, [700, 30]), (64, 7, 3, [224, 449, 1]), (64, 11, 5, [300]),
-                                             (128, 3, 1, [500, 17]), (128, 11, 5, [260, 100]), (128, 7, 1, [2, 223])])
+                                             (128, 3, 1, [500, 17]), (128, 11, 5, [260, 100]), (128, 7, 1, [2, 223]),
+                                             (256, 3, 1, [200, 97]), (256, 11, 5, [130, 96, 1]), (256, 7, 3, [95])])
 @pytest.mark.parametrize("act", [capi.PRE_LRELU, capi.PRE_SNAKE])
 @pytest.mark.parametrize("store", [torch.float32, torch.bfloat16])
 def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act, store):

@@ -23,7 +23,7 @@ def main():
     ops = engine.Ops(dev)
     filt = torch.from_numpy(packing.kaiser_sinc_filter12()).to(dev)
     print(f"{'C':>4} {'k':>3} {'dil':>3} {'act':>6} {'us':>9} {'TFLOP/s':>8} {'GB/s(x+y)':>9}")
-    for C, mult in ((128, 48), (64, 192), (32, 384)):
+    for C, mult in ((256, 8), (128, 48), (64, 192), (32, 384)):
         rows = args.frames * mult
         rag = Ragged([rows] * args.batch, dev)
         R = rag.total_rows
