@@ -67,6 +67,7 @@ PROTOTYPES = {
     "tts_abi_version": (C.c_int, []),
     "tts_conv1d_tile_rows": (C.c_int, [_i, _i]),
     "tts_conv1d_n_tile": (C.c_int, [_i, _i]),
+    "tts_conv1d_small_tile_rows": (C.c_int, [_i, _i, _i]),
     "tts_conv1d": (C.c_int, [C.POINTER(TtsConvDesc), _p]),
     "tts_resblock_step": (C.c_int, [C.POINTER(TtsResblockDesc), _p]),
     "tts_resblock_tile_rows": (C.c_int, [_i]),

@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
 int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st);
 int conv1d_tile_rows(int cout, int mode);
 int conv1d_n_tile(int cout, int mode);
+int conv1d_small_tile_rows(int cout, int mode, int packed_cols);
 int layernorm(const float*, int, float*, int, const float*, const float*, int, int, float, hipStream_t);
 int cond_layernorm(const float*, int, float*, int, const float*, const float*, int, const TtsTile*, int, int, hipStream_t);
 int l2_normalize(const float*, float*, int, int, hipStream_t);
@@ -54,6 +55,7 @@ int tts_abi_version(void) { return 1; }
 
 int tts_conv1d_tile_rows(int32_t cout, int32_t mode) { return tts::conv1d_tile_rows(cout, mode); }
 int tts_conv1d_n_tile(int32_t cout, int32_t mode) { return tts::conv1d_n_tile(cout, mode); }
+int tts_conv1d_small_tile_rows(int32_t cout, int32_t mode, int32_t packed_cols) { return tts::conv1d_small_tile_rows(cout, mode, packed_cols); }
 
 int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream) {
   if (!d) {

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 // ------------------------------------------------------------------------------------------------
 // shape -> tile configuration
 // ------------------------------------------------------------------------------------------------
-enum ConvShape { S_128x128, S_128x96, S_128x64, S_256x32, S_D128x96 };
+enum ConvShape { S_128x128, S_128x96, S_128x64, S_256x32, S_D128x96, S_64x64, S_D64x64 };
 
 static ConvShape pick_shape(int cout, int mode) {
   if (mode != TTS_MODE_LINEAR) return S_D128x96;
@@ -349,7 +349,17 @@ static void shape_dims(ConvShape s, int& bm, int& bn) {
     case S_128x64: bm = 128; bn = 64; break;
     case S_256x32: bm = 256; bn = 32; break;
     case S_D128x96: bm = 128; bn = 96; break;
+    case S_64x64: bm = 64; bn = 64; break;
+    case S_D64x64: bm = 64; bn = 64; break;
   }
+}
+
+// Small-batch form: 64 x 64 tiles (four wavefronts, 2 x 2) put 3-4x more workgroups on the chip when the 128-row
+// grid would leave most CUs idle; the host asks for it by building the tile table with 64 rows.  Needs the packed
+// width (a multiple of 96 or 128 by construction) to also be a multiple of 64.
+static bool small_form_ok(int cout, int mode, int cols) {
+  if (cols % 64 != 0) return false;
+  return mode != TTS_MODE_LINEAR || cout > 64;
 }
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE>
@@ -395,11 +405,12 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.mode != TTS_MODE_COUPLING || d.aux, "conv1d: coupling mode needs aux");
   TTS_CHECK_ARG(d.pre_act != TTS_PRE_SNAKE || (d.snake_alpha && d.snake_beta && d.snake_filt), "conv1d: PRE_SNAKE needs alpha/beta/filter");
   if (d.n_tiles == 0) return TTS_OK;
-  const ConvShape s = pick_shape(d.cout, d.mode);
+  const int cols = d.mode == TTS_MODE_LINEAR ? d.wn : d.half_pad;
+  ConvShape s = pick_shape(d.cout, d.mode);
+  if (d.tile_rows == 64 && small_form_ok(d.cout, d.mode, cols)) s = d.mode == TTS_MODE_LINEAR ? S_64x64 : S_D64x64;
   int bm, bn;
   shape_dims(s, bm, bn);
   TTS_CHECK_ARG(d.tile_rows == bm, "conv1d: tile table built for %d rows, kernel needs %d", d.tile_rows, bm);
-  const int cols = d.mode == TTS_MODE_LINEAR ? d.wn : d.half_pad;
   TTS_CHECK_ARG(cols % bn == 0 && cols >= d.cout, "conv1d: packed width %d not a multiple of the N tile %d (cout %d)", cols, bn, d.cout);
   TTS_CHECK_ARG(d.mode == TTS_MODE_LINEAR || d.wn == 2 * d.half_pad, "conv1d: dual mode needs wn == 2*half_pad");
   switch (s) {
@@ -408,6 +419,8 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
     case S_128x64: return launch_cfg<2, 1, 2, 2, false>(d, st);
     case S_256x32: return launch_cfg<2, 1, 4, 1, false>(d, st);
     case S_D128x96: return launch_cfg<1, 3, 4, 1, true>(d, st);
+    case S_64x64: return launch_cfg<1, 1, 2, 2, false>(d, st);
+    case S_D64x64: return launch_cfg<1, 1, 2, 2, true>(d, st);
   }
   return TTS_E_ARG;
 }
@@ -417,6 +430,8 @@ int conv1d_tile_rows(int cout, int mode) {
   shape_dims(pick_shape(cout, mode), bm, bn);
   return bm;
 }
+
+int conv1d_small_tile_rows(int cout, int mode, int packed_cols) { return small_form_ok(cout, mode, packed_cols) ? 64 : 0; }
 
 int conv1d_n_tile(int cout, int mode) {
   int bm, bn;

@@ -8,6 +8,7 @@ Layout: activations are time-major [rows, channels], all utterances of the batch
 (ragged.py).  The reference mirrors are cited per method.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -45,6 +46,7 @@ class Ops:
         self.lib = capi.lib()
         self.device = torch.device(device)
         self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
+        self.small_tile_blocks = int(os.environ.get("TOUCAN_SMALL_TILE_BLOCKS", "1536"))  # regular conv grids below this many workgroups switch to the 64 x 64 small-batch form (0: never)
         self.default_compute = COMPUTE_F32  # convs whose weights carry a bf16 copy run on bf16 MFMA when this is COMPUTE_BF16
 
     def stream(self):
@@ -59,7 +61,13 @@ class Ops:
              res_scale=1.0, aux=None, accumulate=False, compute=None, snake=None):
         if compute is None:
             compute = self.default_compute
-        tiles, n_tiles = rag.tiles(cw.tile_rows)
+        tile_rows = cw.tile_rows
+        if self.small_tile_blocks and cw.small_tile_rows:
+            # grid of the regular form; when it cannot fill the chip, the 64 x 64 form runs ~3x more workgroups
+            cols = cw.wn if cw.mode == MODE_LINEAR else cw.half_pad
+            if -(-rag.total_rows // cw.tile_rows) * (cols // cw.n_tile) < self.small_tile_blocks:
+                tile_rows = cw.small_tile_rows
+        tiles, n_tiles = rag.tiles(tile_rows)
         d = capi.TtsConvDesc()
         d.x, d.ldx, d.cin = x.data_ptr(), _ld(x), cw.cin
         use_bf16 = compute == COMPUTE_BF16 and cw.w_bf16 is not None
@@ -80,7 +88,7 @@ class Ops:
         d.compute = COMPUTE_BF16 if use_bf16 else COMPUTE_F32
         # bf16 tensors in HBM are recognised by dtype (strides are already in elements)
         d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0)
-        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, cw.tile_rows
+        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
         if tm is not None and tm.wants(cw, d.compute):
             ev0, ev1 = tm.events()

@@ -69,6 +69,7 @@ class ConvWeights:
         half = _roundup(self.cout, self.n_tile)
         self.half_pad = half if dual else 0
         self.wn = 2 * half if dual else half
+        self.small_tile_rows = lib.tts_conv1d_small_tile_rows(self.cout, mode, half)  # 64 or 0 (small-batch form)
         packed = np.zeros((taps, self.cin_pad, self.wn), dtype=np.float32)
         if dual:
             packed[:, :cin, : self.cout] = w_kio[:, :, : self.cout]

@@ -85,13 +85,17 @@ typedef struct {
   int32_t accumulate;
   int32_t compute;     /* 0: fp32 MFMA (exact fp32 fma chain); 1: bf16 MFMA, fp32 accumulate */
   int32_t io_flags;    /* TTS_IO_* bits: which of x / y / res are bf16 tensors in HBM (ld* then count bf16 elements) */
-  const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows; /* tile_rows must match the kernel's BM */
+  const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows; /* tts_conv1d_tile_rows() or the small form's 64 */
 } TtsConvDesc;
 
 /* BM (rows per tile) the conv kernel will use for this shape; build the tile table with it. */
 int tts_conv1d_tile_rows(int32_t cout, int32_t mode);
 /* N tile (columns) for this shape: pack weights with wn = roundup(cols, n_tile). */
 int tts_conv1d_n_tile(int32_t cout, int32_t mode);
+/* Small-batch form: returns 64 when this shape (with its packed width `packed_cols` = wn, or half_pad in the dual
+ * modes) may also run on 64 x 64 tiles - build the tile table with 64 rows and pass tile_rows = 64 to put ~3x more
+ * workgroups on the chip when rows/128 * cols/n_tile would leave CUs idle - else 0. */
+int tts_conv1d_small_tile_rows(int32_t cout, int32_t mode, int32_t packed_cols);
 int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream);
 
 /*

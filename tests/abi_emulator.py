@@ -107,6 +107,9 @@ class Emulator:
     def tts_conv1d_tile_rows(self, cout, mode):
         return self._reallib().tts_conv1d_tile_rows(cout, mode)
 
+    def tts_conv1d_small_tile_rows(self, cout, mode, cols):
+        return self._reallib().tts_conv1d_small_tile_rows(cout, mode, cols)
+
     def tts_conv1d_n_tile(self, cout, mode):
         return self._reallib().tts_conv1d_n_tile(cout, mode)
 

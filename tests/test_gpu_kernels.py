@@ -68,9 +68,14 @@ CONV_CASES = [
 
 @pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", CONV_CASES)
 @pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
-def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute):
+@pytest.mark.parametrize("form", ["regular", "small"])
+def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
+    # form: the regular 128/256-row tiles, or the 64 x 64 small-batch tiles the host picks when the grid is small
     w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
     b = rnd(cout, seed=2, scale=0.1).numpy()
+    if form == "small" and not packing.pack_conv(w, b, "cpu", dil=dil, mode=mode).small_tile_rows:
+        pytest.skip("shape has no small-batch form")
+    gpu.small_tile_blocks = 0 if form == "regular" else 1 << 30
     dual = mode != capi.MODE_LINEAR
     co = cout // 2 if dual else cout
 
@@ -88,7 +93,10 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute):
                  res_scale=0.25, aux=aux, accumulate=True, compute=compute)
         return y
 
-    g, c = both(gpu, cpu, run)
+    try:
+        g, c = both(gpu, cpu, run)
+    finally:
+        gpu.small_tile_blocks = 1536
     close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
 
 
