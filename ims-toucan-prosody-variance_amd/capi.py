@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtoucan_hip.so")
+LIB_PATH = os.environ.get("TOUCAN_HIP_LIB") or os.path.join(_PKG, "libtoucan_hip.so")  # the override is for A/B builds of the library only
 
 MODE_LINEAR, MODE_GLU, MODE_GATED, MODE_COUPLING = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2

@@ -25,6 +25,12 @@ namespace tts {
 __device__ __forceinline__ unsigned short rb_f2bf(float f) { return f32_to_bf16(f); }
 __device__ __forceinline__ float rb_bf2f(unsigned short u) { return bf16_to_f32(u); }
 
+#ifndef RB_C32_WAVES
+#define RB_C32_WAVES 4      // waves per SIMD the C = 32 instantiation is compiled for (tuning knob, see the launch bounds)
+#endif
+#ifndef RB_C32_PREFETCH
+#define RB_C32_PREFETCH 1   // one-chunk-ahead input prefetch in the C = 32 snake (costs 8 registers)
+#endif
 constexpr int RB_LEAD = 16;
 // C <= 128: conv1 on M1 = 256 rows (8 waves), 224 output rows, whole-C weight slabs.
 // C == 256: conv1 on M1 = 128 rows (4 waves, 8 accumulators each), 96 output rows, 64-channel slabs (LDS: t1 alone is 66 KB).
@@ -34,6 +40,15 @@ struct RbCfg {
   static constexpr int BM = M1 - 2 * RB_LEAD;
   static constexpr int THREADS = 2 * M1;
   static constexpr int KC = C == 256 ? 64 : C;
+  // snake over the act1(x) window: item = (8*NCH1 window rows, channel); the window is allocated in whole items so that
+  // the streamed stores need no row bound
+  static constexpr int NCH1 = (C == 32 || C == 256) ? 3 : 5;
+  static constexpr int GR1 = 8 * NCH1;
+  static constexpr int win_alloc(int h1) { return (M1 + 2 * h1 + GR1 - 1) / GR1 * GR1; }
+  // The streamed snake stores come in two equivalent forms; which one the compiler schedules well differs per instantiation
+  // (measured inside one run: C = 32 gains 10 % from the unguarded form; C = 64 and 256 lose 10 % to it - it hoists every
+  // LDS address and spills): unguarded = no row bound (the window is padded to whole items) and one unsigned range compare.
+  static constexpr bool UNGUARDED = C == 32;
 };
 
 // register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
@@ -73,11 +88,11 @@ struct RbSlab {
   }
 };
 
-// waves per SIMD the register allocation must leave room for: 3 / 2 / 1 workgroups per CU (C = 32 / 64 / 128; LDS allows no more)
+// waves per SIMD the register allocation must leave room for: 2 / 2 / 1 / 1 workgroups per CU (C = 32 / 64 / 128 / 256)
 // IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
 template <int C, bool IOB>
-// (measured: the 80-VGPR cap of C = 32 spills a little but 3 workgroups per CU beat 2 without spills: 14.5 vs 17.3 ms per step)
-__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? 6 : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d) {
+// (C = 32: with the prefetching snake two spill-free workgroups per CU beat three at the 80-register cap by ~10 %)
+__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d) {
   constexpr int RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   constexpr int KC = RbCfg<C>::KC;        // channels per weight slab (all of them for C <= 128: one step per tap, act1(x) staged once)
   constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
@@ -93,8 +108,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? 6 : (C == 64 ? 4 : (C
   const int h1 = (d.taps - 1) / 2 * d.dil, h2 = (d.taps - 1) / 2;
   const int win_rows = RB_M1 + 2 * h1;
   // xa (act1(x) window) is dead once conv1 has finished, so t1 (conv1 output) overlays it
-  const size_t xa_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7, t1_elems = (size_t)RB_M1 * TP;
-  unsigned short* xa = reinterpret_cast<unsigned short*>(lds_raw);          // [win_rows][XP]
+  const size_t xa_elems = ((size_t)RbCfg<C>::win_alloc(h1) * XP + 7) & ~(size_t)7, t1_elems = (size_t)RB_M1 * TP;
+  unsigned short* xa = reinterpret_cast<unsigned short*>(lds_raw);          // [win_alloc][XP]
   unsigned short* t1 = xa;                                                  // [M1][TP]
   unsigned short* ws = xa + (xa_elems > t1_elems ? xa_elems : t1_elems);    // [2][SLAB]
 
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? 6 : (C == 64 ? 4 : (C
     const int wbase = l0 - RB_LEAD - h1;
     if (snake) {
       // anti-aliased snake while staging: item = (8*NCH1 window rows, channel), streamed so that only the first chunk pays the halo
-      constexpr int NCH1 = (C == 32 || C == 256) ? 3 : 5, GR = 8 * NCH1;
+      constexpr int NCH1 = RbCfg<C>::NCH1, GR = RbCfg<C>::GR1;
       const int items = ((win_rows + GR - 1) / GR) * KC;
       for (int it = tid; it < items; it += RB_THREADS) {
         const int chl = it % KC, wr0 = (it / KC) * GR;
@@ -148,15 +163,17 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? 6 : (C == 64 ? 4 : (C
         if (live) {
           const float ea = expf(d.alpha1[cg]), ib = 1.0f / (expf(d.beta1[cg]) + 1e-9f);
           auto st = [&](int i, float v) {
-            if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = rb_f2bf((t0 + i >= 0 && t0 + i < T) ? v : 0.0f);
+            if constexpr (RbCfg<C>::UNGUARDED)
+              xa[(wr0 + i) * XP + chl] = rb_f2bf((unsigned)(t0 + i) < (unsigned)T ? v : 0.0f);
+            else if (wr0 + i < win_rows)
+              xa[(wr0 + i) * XP + chl] = rb_f2bf((t0 + i >= 0 && t0 + i < T) ? v : 0.0f);
           };
           if constexpr (IOB)
-            snake_stream<NCH1>([&](int q) { return rb_bf2f(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, st, T, t0, f, ea, ib);
+            snake_stream<NCH1, C != 32 || RB_C32_PREFETCH>([&](int q) { return rb_bf2f(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, st, T, t0, f, ea, ib);
           else
-            snake_stream<NCH1>([&](int q) { return d.x[(size_t)(tile.seq_begin + q) * d.ldx + cg]; }, st, T, t0, f, ea, ib);
+            snake_stream<NCH1, C != 32 || RB_C32_PREFETCH>([&](int q) { return d.x[(size_t)(tile.seq_begin + q) * d.ldx + cg]; }, st, T, t0, f, ea, ib);
         } else {
-          for (int i = 0; i < GR; ++i)
-            if (wr0 + i < win_rows) xa[(wr0 + i) * XP + chl] = 0;
+          for (int i = 0; i < GR; ++i) xa[(wr0 + i) * XP + chl] = 0;
         }
       }
     } else if constexpr (IOB) {
@@ -292,11 +309,11 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? 6 : (C == 64 ? 4 : (C
 #pragma unroll
         for (int i = 0; i < GR; ++i) o[q][i] = 0.0f;
         if (live) {
-          snake_stream<NCH2>([&](int q2) {
+          snake_stream<NCH2, C != 32 || RB_C32_PREFETCH>([&](int q2) {
             int i = q2 - base;
             i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);  // only reached by rows whose outputs are not consumed
             return rb_bf2f(t1[i * TP + chn]);
-          }, [&](int i, float v) { o[q][i] = (t0 + i >= 0 && t0 + i < T) ? v : 0.0f; }, T, t0, f, expf(d.alpha2[chn]),
+          }, [&](int i, float v) { o[q][i] = (RbCfg<C>::UNGUARDED ? (unsigned)(t0 + i) < (unsigned)T : (t0 + i >= 0 && t0 + i < T)) ? v : 0.0f; }, T, t0, f, expf(d.alpha2[chn]),
                              1.0f / (expf(d.beta2[chn]) + 1e-9f));
         }
       }
@@ -397,7 +414,7 @@ template <int C, bool IOB>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   constexpr int KC = RbCfg<C>::KC, RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   const int h1 = (d.taps - 1) / 2 * d.dil;
-  const size_t xa = (((size_t)(RB_M1 + 2 * h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
+  const size_t xa = (((size_t)RbCfg<C>::win_alloc(h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
   size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * KC * C) * 2;
   if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);

@@ -76,22 +76,48 @@ __device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const 
 // Streaming form: 8*NCH consecutive frames starting at local frame t0.  Chunk c reuses the last 12 input frames and the
 // last 10 2x-rate samples of chunk c-1 (they are exactly the halo it would otherwise recompute), so only the first chunk
 // pays the (26 samples / 8 frames) halo overhead of snake_rows_fn; with NCH = 5 the up-sampler + sine work per frame drops
-// from 3.25 to 2.25 samples.  store(i, v) receives frame t0+i (callers mask frames outside [0, T)).
-template <int NCH, class LoadFn, class StoreFn>
+// from 3.25 to 2.25 samples.  store(i, v) receives frame t0+i (callers mask frames outside [0, T)).  The 8 frames a chunk
+// adds are requested one chunk ahead (reads run up to 21 frames ahead of the stores), so their latency hides under the math.
+// PREFETCH = false keeps 8 registers free (the 80-register C = 32 residual step is faster without it).
+template <int NCH, bool PREFETCH = true, class LoadFn, class StoreFn>
 __device__ __forceinline__ void snake_stream(LoadFn load, StoreFn store, int T, int t0, const float (&f)[12], float ea, float inv_b) {
+  // The factor 2 of the zero-stuffed interpolation is carried as a scale: h = u/2 and s/2 = h + (1/2b) sin^2(2h e^alpha) are
+  // what the registers hold, and the 12-tap decimator output is doubled once per frame (one multiply per frame instead of
+  // one per 2x-rate sample, and no second set of taps in scalar registers).
+  const float er = ea * 0.3183098861837907f;  // phase in revolutions per unit of h
+  const float hb = 0.5f * inv_b;
   float xin[20];  // x[tc-6 .. tc+13] of the current chunk
+  float nxt[8];   // the 8 frames the next chunk adds, requested one chunk ahead so their latency hides under this chunk's math
   float s[26];    // s[m] <-> n = 2*tc - 5 + m
+#pragma unroll
+  for (int i = 0; i < 20; ++i) {
+    int q = t0 - 6 + i;
+    q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
+    xin[i] = load(q);
+  }
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int tc = t0 + 8 * c;
+    if (c > 0) {
 #pragma unroll
-    for (int i = 0; i < 20; ++i) {
-      if (c > 0 && i < 12) {
-        xin[i] = xin[i + 8];  // ascending i: the source slot is overwritten only later in this loop
-      } else {
-        int q = tc - 6 + i;
+      for (int i = 0; i < 12; ++i) xin[i] = xin[i + 8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (PREFETCH) {
+          xin[12 + i] = nxt[i];
+        } else {
+          int q = tc + 6 + i;
+          q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
+          xin[12 + i] = load(q);
+        }
+      }
+    }
+    if (PREFETCH && c + 1 < NCH) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int q = tc + 14 + i;
         q = q < 0 ? 0 : (q > T - 1 ? T - 1 : q);
-        xin[i] = load(q);
+        nxt[i] = load(q);
       }
     }
 #pragma unroll
@@ -100,16 +126,18 @@ __device__ __forceinline__ void snake_stream(LoadFn load, StoreFn store, int T, 
         s[m] = s[m + 16];  // positions 2tc-5 .. 2tc+4 were the tail of the previous chunk (already edge-corrected)
       } else {
         const int qi = 3 + ((m + 1) >> 1);
-        float u = 0.f;
+        float u;
         if (((m + 1) & 1) == 0) {
+          u = xin[qi - 3] * f[11];
 #pragma unroll
-          for (int d = -3; d <= 2; ++d) u = fmaf(xin[qi + d], f[5 - 2 * d], u);
+          for (int d = -2; d <= 2; ++d) u = fmaf(xin[qi + d], f[5 - 2 * d], u);
         } else {
+          u = xin[qi - 2] * f[10];
 #pragma unroll
-          for (int d = -2; d <= 3; ++d) u = fmaf(xin[qi + d], f[6 - 2 * d], u);
+          for (int d = -1; d <= 3; ++d) u = fmaf(xin[qi + d], f[6 - 2 * d], u);
         }
-        u *= 2.0f;
-        s[m] = fmaf(inv_b, sin_sq(u * ea), u);
+        const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(u * er));  // v_sin takes revolutions; sin(2 pi frac(r)) == sin(2 pi r)
+        s[m] = fmaf(hb, sn * sn, u);
       }
     }
     const int nbase = 2 * tc - 5;
@@ -128,10 +156,10 @@ __device__ __forceinline__ void snake_stream(LoadFn load, StoreFn store, int T, 
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      float a = 0.f;
+      float a = s[2 * i] * f[0];
 #pragma unroll
-      for (int k = 0; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
-      store(8 * c + i, a);
+      for (int k = 1; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
+      store(8 * c + i, 2.0f * a);
     }
   }
 }
