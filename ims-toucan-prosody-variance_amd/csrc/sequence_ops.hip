@@ -265,50 +265,53 @@ int glow_invconv_actnorm(float* x, int ldx, int rows, int c, const float* winv, 
 // Each thread: one channel x ROWS consecutive frames; the 2x-rate signal exists only in registers
 // (2*ROWS+10 values), so the up-sampled tensor never touches LDS or HBM.
 // ------------------------------------------------------------------------------------------------
-template <int ROWS>
+template <int NCH, bool XB, bool YB>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const float* __restrict__ filt, int c, const TtsTile* __restrict__ tiles,
-                                                       int tile_rows, int io_flags) {
+                                                       int tile_rows) {
   const TtsTile t = tiles[blockIdx.x];
-  // work item = (group of ROWS frames, channel); consecutive threads take consecutive channels, so a wavefront
-  // reads 256 contiguous bytes per row (two 128-byte rows when c == 32).  The 2x-rate signal lives in registers only.
+  // work item = (8*NCH frames, channel), streamed (snake.h) so that only the first 8 frames pay the filter halo; consecutive
+  // threads take consecutive channels, so a wavefront touches one contiguous run per row.  The 2x-rate signal lives in registers.
+  constexpr int GR = 8 * NCH;
   const int item = blockIdx.y * 256 + threadIdx.x;
   const int ch = item % c;
   const int g = item / c;
-  if (g * ROWS >= tile_rows) return;
-  const int r0 = t.row0 + g * ROWS;
+  if (g * GR >= tile_rows) return;
+  const int r0 = t.row0 + g * GR;
   if (r0 >= t.seq_end) return;
+  const int r_end = min(t.seq_end, t.row0 + tile_rows);  // rows past the tile belong to the next tile's workgroup
   float f[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) f[k] = filt[k];
   const float ea = expf(alpha[ch]);
   const float inv_b = 1.0f / (expf(beta[ch]) + 1e-9f);
-  float out[ROWS];
-  if (io_flags & TTS_IO_X_BF16) {
-    const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(x);
-    snake_rows_fn<ROWS>([&](int q) { return bf16_to_f32(xh[(size_t)(t.seq_begin + q) * ldx + ch]); }, t.seq_end - t.seq_begin,
-                        r0 - t.seq_begin, f, ea, inv_b, out);
-  } else {
-    snake_rows<ROWS>(x, ldx, ch, t.seq_begin, t.seq_end - t.seq_begin, r0 - t.seq_begin, f, ea, inv_b, out);
-  }
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    if (r0 + i >= t.seq_end) break;
-    if (io_flags & TTS_IO_Y_BF16)
-      reinterpret_cast<unsigned short*>(y)[(size_t)(r0 + i) * ldy + ch] = f32_to_bf16(out[i]);
-    else
-      y[(size_t)(r0 + i) * ldy + ch] = out[i];
-  }
+  const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(x);
+  unsigned short* __restrict__ yh = reinterpret_cast<unsigned short*>(y);
+  snake_stream<NCH>([&](int q) { return XB ? bf16_to_f32(xh[(size_t)(t.seq_begin + q) * ldx + ch]) : x[(size_t)(t.seq_begin + q) * ldx + ch]; },
+                    [&](int i, float v) {
+                      if (r0 + i < r_end) {
+                        if (YB) yh[(size_t)(r0 + i) * ldy + ch] = f32_to_bf16(v);
+                        else y[(size_t)(r0 + i) * ldy + ch] = v;
+                      }
+                    }, t.seq_end - t.seq_begin, r0 - t.seq_begin, f, ea, inv_b);
 }
 
 int snake_aa(const float* x, int ldx, float* y, int ldy, const float* alpha, const float* beta, const float* filt, int c,
              const TtsTile* tiles, int n_tiles, int tile_rows, int io_flags, hipStream_t st) {
   TTS_CHECK_ARG(tile_rows % 8 == 0, "snake_aa: tile_rows must be a multiple of 8");
   if (n_tiles == 0) return TTS_OK;
-  const int items = (tile_rows / 8) * c;
+  constexpr int NCH = 4;
+  const int items = ((tile_rows + 8 * NCH - 1) / (8 * NCH)) * c;
   dim3 grid(n_tiles, (items + 255) / 256), block(256);
-  hipLaunchKernelGGL(snake_aa_kernel<8>, grid, block, 0, st, x, ldx, y, ldy, alpha, beta, filt, c, tiles, tile_rows, io_flags);
+  const bool xb = io_flags & TTS_IO_X_BF16, yb = io_flags & TTS_IO_Y_BF16;
+#define TTS_SNAKE_LAUNCH(XB, YB) \
+  hipLaunchKernelGGL((snake_aa_kernel<NCH, XB, YB>), grid, block, 0, st, x, ldx, y, ldy, alpha, beta, filt, c, tiles, tile_rows)
+  if (xb && yb) TTS_SNAKE_LAUNCH(true, true);
+  else if (xb) TTS_SNAKE_LAUNCH(true, false);
+  else if (yb) TTS_SNAKE_LAUNCH(false, true);
+  else TTS_SNAKE_LAUNCH(false, false);
+#undef TTS_SNAKE_LAUNCH
   return launch_status("snake_aa");
 }
 

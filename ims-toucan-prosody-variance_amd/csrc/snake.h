@@ -10,15 +10,9 @@
 
 namespace tts {
 
-// sin^2(a) with one hardware sine: a/(2*pi) is reduced to [-0.5, 0.5] revolutions, v_sin_f32 takes revolutions.
-// Absolute error ~1e-6 for |a| up to a few hundred radians (tests/test_gpu_kernels.py::test_snake_aa checks it against
-// the fp64 emulator), versus ~1e-7 for ocml's sinf at 5x the cost and 3x the registers.
-__device__ __forceinline__ float sin_sq(float a) {
-  float t = a * 0.15915494309189535f;
-  t -= rintf(t);
-  const float sn = __builtin_amdgcn_sinf(t);
-  return sn * sn;
-}
+// The sine is one hardware v_sin_f32 (argument in revolutions, reduced by v_fract_f32): absolute error ~1e-6 for phases up to
+// a few hundred radians (tests/test_gpu_kernels.py::test_snake_aa checks it against the fp64 emulator), versus ~1e-7 for
+// ocml's sinf at 5x the cost and 3x the registers.
 
 // out[i] = snake_aa(x)[t0 + i] for i < ROWS; t0 is the local frame index inside an utterance of T frames; load(q) returns
 // frame q of the utterance (0 <= q < T, already clamped).  t0 may be negative / rows may lie beyond T: those outputs are
@@ -26,6 +20,7 @@ __device__ __forceinline__ float sin_sq(float a) {
 template <int ROWS, class LoadFn>
 __device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const float (&f)[12], float ea, float inv_b, float (&out)[ROWS]) {
   constexpr int NX = ROWS + 12, NS = 2 * ROWS + 10;
+  const float er = ea * 0.3183098861837907f, hb = 0.5f * inv_b;
   float xin[NX];  // x[t0-6 .. t0+ROWS+5], replicate padded inside the utterance
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
@@ -38,7 +33,7 @@ __device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const 
   for (int m = 0; m < NS; ++m) {
     // q = floor(n/2) = t0 - 3 + ((m+1)>>1);  xin index of x[q+d] = 3 + ((m+1)>>1) + d
     const int qi = 3 + ((m + 1) >> 1);
-    float u = 0.f;
+    float u = 0.f;  // h = u/2 (see snake_stream: the factor 2 is applied once per output frame)
     if (((m + 1) & 1) == 0) {  // n even (m odd): taps f[5-2d], d = -3..2
 #pragma unroll
       for (int d = -3; d <= 2; ++d) u = fmaf(xin[qi + d], f[5 - 2 * d], u);
@@ -46,8 +41,8 @@ __device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const 
 #pragma unroll
       for (int d = -2; d <= 3; ++d) u = fmaf(xin[qi + d], f[6 - 2 * d], u);
     }
-    u *= 2.0f;
-    s[m] = fmaf(inv_b, sin_sq(u * ea), u);
+    const float sn = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(u * er));
+    s[m] = fmaf(hb, sn * sn, u);
   }
   // replicate padding of the 2x-rate signal: positions n < 0 take s[n=0], n > 2T-1 take s[n=2T-1]
   const int nbase = 2 * t0 - 5;
@@ -69,7 +64,7 @@ __device__ __forceinline__ void snake_rows_fn(LoadFn load, int T, int t0, const 
     float a = 0.f;
 #pragma unroll
     for (int k = 0; k < 12; ++k) a = fmaf(s[2 * i + k], f[k], a);
-    out[i] = a;
+    out[i] = 2.0f * a;
   }
 }
 

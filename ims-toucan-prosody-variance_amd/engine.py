@@ -190,10 +190,10 @@ class Ops:
                                                      self.stream()), "tts_glow_invconv_actnorm")
 
     def snake_aa(self, x, y, alpha, beta, filt, c, rag):
-        tiles, n = rag.tiles(64)
+        tiles, n = rag.tiles(256)  # 8 streamed groups of 32 frames per tile: 256 work items already at c = 32
         flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0)
         capi.check(self.lib.tts_snake_aa(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), alpha.data_ptr(), beta.data_ptr(), filt.data_ptr(), c,
-                                         tiles.data_ptr(), n, 64, flags, self.stream()), "tts_snake_aa")
+                                         tiles.data_ptr(), n, 256, flags, self.stream()), "tts_snake_aa")
         return y
 
     def conv_post(self, x, cin, w, bias, pre, slope, wav, rag):
