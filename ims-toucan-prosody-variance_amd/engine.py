@@ -679,13 +679,13 @@ class VocoderEngine:
             # transposed conv as a 3-tap polyphase conv; [R, u*ch] re-viewed as [R*u, ch]
             # stages that run the fused residual step keep their residual stream as bf16 in HBM (bandwidth-bound kernels)
             fused = self.fuse_step and ch <= self.fuse_max_channels
-            sdt = torch.bfloat16 if (fused and self.store_bf16) else torch.float32
+            sdt = torch.bfloat16 if self.store_bf16 else torch.float32  # (the unfused C = 256 stage included: its convs and snakes take bf16 I/O)
             y = ops.conv(self.ups[i], x, ops.empty(R, u * ch, dtype=sdt), rag, pre=PRE_NONE if big else PRE_LRELU, pre_slope=0.1, compute=cp)
             R, rag = R * u, rag.scaled(u)
             xs = y.view(R, ch)
             stage_out = ops.empty(R, ch, dtype=sdt)
-            t1 = None if fused else ops.empty(R, ch)
-            t2, sa = (ops.empty(R, ch), ops.empty(R, ch)) if (big and not self.fuse_snake and not fused) else (None, None)
+            t1 = None if fused else ops.empty(R, ch, dtype=sdt)
+            t2, sa = (ops.empty(R, ch, dtype=sdt), ops.empty(R, ch, dtype=sdt)) if (big and not self.fuse_snake and not fused) else (None, None)
             for j in range(3):
                 cur = xs
                 bufs = [ops.empty(R, ch, dtype=sdt), ops.empty(R, ch, dtype=sdt)]
@@ -725,7 +725,7 @@ class VocoderEngine:
                 taps[f"voc_stage{i}"] = x.float()
         wav = ops.empty(R)
         if big:
-            t = ops.snake_aa(x, ops.empty(R, ch), *self.post_snake, self.filt, ch, rag)
+            t = ops.snake_aa(x, ops.empty(R, ch, dtype=x.dtype), *self.post_snake, self.filt, ch, rag)
             ops.conv_post(t, ch, self.post_w, self.post_b, PRE_NONE, 0.0, wav, rag)
         else:
             ops.conv_post(x, ch, self.post_w, self.post_b, PRE_LRELU, 0.01, wav, rag)  # InferenceAvocodo.py:53
