@@ -49,6 +49,10 @@ struct RbCfg {
   // (measured inside one run: C = 32 gains 10 % from the unguarded form; C = 64 and 256 lose 10 % to it - it hoists every
   // LDS address and spills): unguarded = no row bound (the window is padded to whole items) and one unsigned range compare.
   static constexpr bool UNGUARDED = C == 32;
+  // taps per weight slab: a slab step costs one workgroup barrier, and at C = 32 / 64 a single tap is only 2 / 8 MFMAs per
+  // wave: C = 32 moves a whole conv per step (<= 22 KB; lrelu step -8..-22 %, snake step -3..-11 % measured).  Two taps per
+  // step at C = 64 measured neutral and doubled the scalar-register spills, so it keeps one
+  static constexpr int TPS = C == 32 ? 11 : 1;
 };
 
 // register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
@@ -57,34 +61,37 @@ template <int UNITS, int UPT, int THREADS>
 struct RbSlab {
   static_assert(UPT >= 1 && UPT <= 8, "slab register staging holds at most 8 units per thread");
   uint4 r0, r1, r2, r3, r4, r5, r6, r7;
-  static __device__ __forceinline__ uint4 ld(const unsigned short* __restrict__ src, int tid, int q) {
+  int n_units;  // units the staged slab really holds (set by load, bounds the store)
+  // n = 16-byte units this slab really holds (the last slab of a conv may carry fewer taps than the others)
+  static __device__ __forceinline__ uint4 ld(const unsigned short* __restrict__ src, int tid, int q, int n) {
     int u = tid + q * THREADS;
-    u = u < UNITS ? u : UNITS - 1;
+    u = u < n ? u : n - 1;
     return *reinterpret_cast<const uint4*>(src + (size_t)u * 8);
   }
-  static __device__ __forceinline__ void st(unsigned short* dst, int tid, int q, const uint4& v) {
+  static __device__ __forceinline__ void st(unsigned short* dst, int tid, int q, const uint4& v, int n) {
     const int u = tid + q * THREADS;
-    if (u < UNITS) *reinterpret_cast<uint4*>(dst + (size_t)u * 8) = v;
+    if (u < n) *reinterpret_cast<uint4*>(dst + (size_t)u * 8) = v;
   }
-  __device__ __forceinline__ void load(const unsigned short* __restrict__ src, int tid) {
-    r0 = ld(src, tid, 0);
-    if constexpr (UPT > 1) r1 = ld(src, tid, 1);
-    if constexpr (UPT > 2) r2 = ld(src, tid, 2);
-    if constexpr (UPT > 3) r3 = ld(src, tid, 3);
-    if constexpr (UPT > 4) r4 = ld(src, tid, 4);
-    if constexpr (UPT > 5) r5 = ld(src, tid, 5);
-    if constexpr (UPT > 6) r6 = ld(src, tid, 6);
-    if constexpr (UPT > 7) r7 = ld(src, tid, 7);
+  __device__ __forceinline__ void load(const unsigned short* __restrict__ src, int tid, int n) {
+    n_units = n;
+    r0 = ld(src, tid, 0, n);
+    if constexpr (UPT > 1) r1 = ld(src, tid, 1, n);
+    if constexpr (UPT > 2) r2 = ld(src, tid, 2, n);
+    if constexpr (UPT > 3) r3 = ld(src, tid, 3, n);
+    if constexpr (UPT > 4) r4 = ld(src, tid, 4, n);
+    if constexpr (UPT > 5) r5 = ld(src, tid, 5, n);
+    if constexpr (UPT > 6) r6 = ld(src, tid, 6, n);
+    if constexpr (UPT > 7) r7 = ld(src, tid, 7, n);
   }
   __device__ __forceinline__ void store(unsigned short* dst, int tid) const {
-    st(dst, tid, 0, r0);
-    if constexpr (UPT > 1) st(dst, tid, 1, r1);
-    if constexpr (UPT > 2) st(dst, tid, 2, r2);
-    if constexpr (UPT > 3) st(dst, tid, 3, r3);
-    if constexpr (UPT > 4) st(dst, tid, 4, r4);
-    if constexpr (UPT > 5) st(dst, tid, 5, r5);
-    if constexpr (UPT > 6) st(dst, tid, 6, r6);
-    if constexpr (UPT > 7) st(dst, tid, 7, r7);
+    st(dst, tid, 0, r0, n_units);
+    if constexpr (UPT > 1) st(dst, tid, 1, r1, n_units);
+    if constexpr (UPT > 2) st(dst, tid, 2, r2, n_units);
+    if constexpr (UPT > 3) st(dst, tid, 3, r3, n_units);
+    if constexpr (UPT > 4) st(dst, tid, 4, r4, n_units);
+    if constexpr (UPT > 5) st(dst, tid, 5, r5, n_units);
+    if constexpr (UPT > 6) st(dst, tid, 6, r6, n_units);
+    if constexpr (UPT > 7) st(dst, tid, 7, r7, n_units);
   }
 };
 
@@ -99,7 +106,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   constexpr int TP = C + 8;               // t1 pitch
   constexpr int TN = C / 32;              // 32-column accumulators per wave
   constexpr int NCH = C / KC;             // slabs per conv
-  constexpr int SLAB = KC * C;            // bf16 elements of one weight slab [KC/8][C][8]
+  constexpr int TPS = RbCfg<C>::TPS;      // taps per weight slab
+  constexpr int TAPW = KC * C;            // bf16 elements of one tap of a slab [KC/8][C][8]
+  constexpr int SLAB = TPS * TAPW;        // one weight slab
   constexpr int UNITS = SLAB / 8;         // 16-byte units
   constexpr int UPT = (UNITS + RB_THREADS - 1) / RB_THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -118,19 +127,28 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
   const bool snake = d.act == TTS_PRE_SNAKE;
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
-  const int steps1 = NCH * d.taps, total_steps = 2 * steps1;
+  const int spc = (d.taps + TPS - 1) / TPS;  // slab steps per channel chunk
+  const int steps1 = NCH * spc, total_steps = 2 * steps1;
+  const int slab_alloc = (d.taps < TPS ? d.taps : TPS) * TAPW;  // LDS elements per slab buffer
 
   RbSlab<UNITS, UPT, RB_THREADS> wreg;
   // weight slab of step `step`: conv1 steps first, then conv2 (global layout [tap][C/8][C][8], one slab = one tap here)
+  // (with TPS > 1 there is one channel chunk, so the taps of a slab are contiguous in global memory)
+  static_assert(TPS == 1 || NCH == 1, "multi-tap slabs need whole-C slabs");
   auto slab_src = [&](int step) __attribute__((always_inline)) {
     const bool second = step >= steps1;
     const int sidx = second ? step - steps1 : step;
-    const int chunk = sidx / d.taps, tap = sidx % d.taps;
+    const int chunk = sidx / spc, tap = (sidx % spc) * TPS;
     const unsigned short* W = reinterpret_cast<const unsigned short*>(second ? d.w2 : d.w1);
     return W + ((size_t)tap * (C / 8) + chunk * (KC / 8)) * C * 8;
   };
-#define load_slab(step_) wreg.load(slab_src(step_), tid)
-#define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * SLAB, tid)
+  auto slab_units = [&](int step) __attribute__((always_inline)) {
+    const int tap = ((step >= steps1 ? step - steps1 : step) % spc) * TPS;
+    const int nt = d.taps - tap < TPS ? d.taps - tap : TPS;
+    return nt * (TAPW / 8);
+  };
+#define load_slab(step_) wreg.load(slab_src(step_), tid, slab_units(step_))
+#define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * slab_alloc, tid)
   load_slab(0);
   store_slab(0);
 
@@ -239,17 +257,21 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         }
       }
     }
-    for (int tap = 0; tap < d.taps; ++tap, ++step) {
+    for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       __syncthreads();
       load_slab(step + 1);  // step + 1 < total_steps always holds here (conv2 follows)
-      const unsigned short* wb = ws + (size_t)(step & 1) * SLAB;
+      const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
+      for (int tt = 0; tt < nt; ++tt) {
+        const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
+        const int tap = tap0 + tt;
 #pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + (wave * 32 + lrow + tap * d.dil) * XP + ks * 16 + lk * 8);
+        for (int ks = 0; ks < KC / 16; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + (wave * 32 + lrow + tap * d.dil) * XP + ks * 16 + lk * 8);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+          }
         }
       }
       store_slab((step + 1) & 1);
@@ -330,19 +352,23 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 
   // ------------------------------------------------------------------ conv2 (dilation 1) over t1; output row o <-> t1 row LEAD + o
   for (int ch = 0; ch < NCH; ++ch) {
-    for (int tap = 0; tap < d.taps; ++tap, ++step) {
+    for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       __syncthreads();
       const bool more = step + 1 < total_steps;
       if (more) load_slab(step + 1);
       if (wave < RB_BM / 32) {
-        const unsigned short* wb = ws + (size_t)(step & 1) * SLAB;
+        const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
+        for (int tt = 0; tt < nt; ++tt) {
+          const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
+          const int tap = tap0 + tt;
 #pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + ks * 16 + lk * 8);
+          for (int ks = 0; ks < KC / 16; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + ks * 16 + lk * 8);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+              const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
           }
         }
       }
@@ -415,7 +441,8 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   constexpr int KC = RbCfg<C>::KC, RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   const int h1 = (d.taps - 1) / 2 * d.dil;
   const size_t xa = (((size_t)RbCfg<C>::win_alloc(h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
-  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * KC * C) * 2;
+  const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2;
   if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB>;
