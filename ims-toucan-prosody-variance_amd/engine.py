@@ -90,12 +90,12 @@ class Ops:
         d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0)
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
-        if tm is not None and tm.wants(cw, d.compute):
+        if tm is not None and tm.wants(cw, d.compute, tile_rows):
             ev0, ev1 = tm.events()
             ev0.record()
             capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
             ev1.record()
-            tm.add(cw, d.compute, sum(rag.lengths), ev0, ev1)
+            tm.add(cw, d.compute, sum(rag.lengths), ev0, ev1, tile_rows)
         else:
             capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
         return y

@@ -10,9 +10,14 @@ import torch
 from . import capi
 
 
-def kernel_class(cw, compute):
+def kernel_class(cw, compute, tile_rows=None):
+    """Name of the conv1d instantiation a launch runs: precision, tile (the 64 x 64 small-batch form when the host asked
+    for 64-row tiles on a shape whose regular form is larger) and dual-accumulator mode."""
     dual = cw.mode != capi.MODE_LINEAR
-    return "conv1d_%s<%dx%d%s>" % ("bf16" if compute == capi.COMPUTE_BF16 else "f32", cw.tile_rows, cw.n_tile, ",dual" if dual else "")
+    bm, bn = cw.tile_rows, cw.n_tile
+    if tile_rows is not None and tile_rows != cw.tile_rows:
+        bm, bn = tile_rows, 64
+    return "conv1d_%s<%dx%d%s>" % ("bf16" if compute == capi.COMPUTE_BF16 else "f32", bm, bn, ",dual" if dual else "")
 
 
 class ConvTimer:
@@ -21,8 +26,8 @@ class ConvTimer:
         self.records = []
         self.enabled = True
 
-    def wants(self, cw, compute):
-        return self.enabled and (self.select is None or kernel_class(cw, compute) in self.select)
+    def wants(self, cw, compute, tile_rows=None):
+        return self.enabled and (self.select is None or kernel_class(cw, compute, tile_rows) in self.select)
 
     def wants_name(self, name):
         return self.enabled and (self.select is None or name in self.select)
@@ -33,10 +38,10 @@ class ConvTimer:
     def events(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def add(self, cw, compute, rows, ev0, ev1):
+    def add(self, cw, compute, rows, ev0, ev1, tile_rows=None):
         ctot = cw.cout * (2 if cw.mode != capi.MODE_LINEAR else 1)
         flops = 2.0 * rows * cw.cin * ctot * cw.algo_taps
-        self.records.append((kernel_class(cw, compute), flops, ev0, ev1))
+        self.records.append((kernel_class(cw, compute, tile_rows), flops, ev0, ev1))
 
     def summary(self):
         """class -> dict(launches, total_ms, avg_us, flops_per_launch, tflops). Call after a device sync."""
