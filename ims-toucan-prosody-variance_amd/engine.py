@@ -657,7 +657,8 @@ class VocoderEngine:
         self.post_b = float(sd[post + ".bias"][0])
         if kind == "bigvgan":
             self.post_snake = (_dev(sd["activation_post.act.alpha"], dev), _dev(sd["activation_post.act.beta"], dev))
-            self.filt = _dev(packing.kaiser_sinc_filter12(), dev)
+            stored = packing.stored_antialias_filter(sd)  # real checkpoints carry the filter as buffers; fixtures do not
+            self.filt = _dev(packing.kaiser_sinc_filter12() if stored is None else stored, dev)
 
     @torch.inference_mode()
     def forward(self, mel_packed, rag, taps=None):

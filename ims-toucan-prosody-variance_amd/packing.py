@@ -138,6 +138,25 @@ def rel_pos_encoding(pmax, d=192):
     return pe
 
 
+def stored_antialias_filter(sd):
+    """The anti-alias filter a BigVGAN checkpoint stores as buffers of its Activation1d modules
+    (``...upsample.filter`` / ``...downsample.lowpass.filter``, [1,1,12]) - None when the state dict has none (then
+    ``kaiser_sinc_filter12`` restates the package's design formula).  The kernels use ONE 12-tap filter for the 2x
+    up- and down-sampler of every activation, which is what the package builds; a checkpoint whose stored filters differ
+    from each other is refused instead of being silently approximated."""
+    keys = sorted(k for k in sd if k.endswith("upsample.filter") or k.endswith("downsample.lowpass.filter"))
+    if not keys:
+        return None
+    first = _np(sd[keys[0]]).reshape(-1).astype(np.float32)
+    if first.size != 12:
+        raise NotImplementedError(f"{keys[0]}: {first.size}-tap anti-alias filter, the kernels implement the 12-tap 2x design")
+    for k in keys[1:]:
+        other = _np(sd[k]).reshape(-1).astype(np.float32)
+        if other.shape != first.shape or not np.allclose(other, first, rtol=0.0, atol=1e-7):
+            raise NotImplementedError(f"{k} differs from {keys[0]}: per-activation anti-alias filters are not supported")
+    return first
+
+
 def kaiser_sinc_filter12():
     """alias_free_torch's kaiser_sinc_filter1d(cutoff 0.25, half_width 0.3, 12 taps) - third party, PARITY UNPINNED.
     A = 2.285*(K/2-1)*pi*4*half_width + 7.95; beta from Kaiser's formula; h = 2c*w*sinc(2c*t), normalised to sum 1."""

@@ -379,7 +379,9 @@ class VocoderOracle:
         assert kind in ("bigvgan", "hifigan")
         self.kind = kind
         self.sd = fold_weight_norm(to_torch(sd_np))
-        self.filt = kaiser_sinc_filter()
+        # a checkpoint that stores the Activation1d filter buffers (alias_free_torch registers them) overrides the restated design
+        stored = sorted(k for k in self.sd if k.endswith("upsample.filter") or k.endswith("downsample.lowpass.filter"))
+        self.filt = self.sd[stored[0]].reshape(-1).to(torch.float32) if stored else kaiser_sinc_filter()
 
     def _names(self):
         if self.kind == "bigvgan":
