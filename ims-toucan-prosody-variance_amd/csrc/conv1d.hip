@@ -72,8 +72,15 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   const int n0 = blockIdx.y * BN;  // first output column (within a half in dual mode)
   const int halo = (d.taps - 1) * d.dil;
   const int win_rows = BM + halo;
-  ET* xs = reinterpret_cast<ET*>(lds_raw);                                  // [win_rows][XP]
-  ET* ws = xs + (((size_t)win_rows * XP + 7) & ~(size_t)7);                 // [2][NH][BK*BN]
+  // The 64-row small-batch form keeps TWO activation windows (a window is only 8-20 KB there): the window of channel slab
+  // ch+1 is requested into registers while slab ch multiplies and written to the other buffer afterwards, so a slab boundary
+  // no longer exposes a global-load round trip (at batch 1 that round trip, not the MFMAs, set the step time: ~2.5 us/slab).
+  constexpr bool WIN2 = BM == 64 && !SNAKE;
+  constexpr int GPR = BK / 4;                        // 4-channel groups per window row
+  constexpr int PF = BF16 ? 5 : 3;                   // 16-byte register groups per thread: (64 + 16) rows x GPR / 256, rounded up
+  const size_t xs_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7;
+  ET* xs0 = reinterpret_cast<ET*>(lds_raw);                                 // [1 or 2][win_rows][XP]
+  ET* ws = xs0 + (WIN2 ? 2 : 1) * xs_elems;                                 // [2][NH][BK*BN]
   constexpr int WBUF = NH * BK * BN;
 
   const int tid = threadIdx.x;
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   const bool x_bf16 = d.io_flags & TTS_IO_X_BF16;
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // the input viewed as bf16
   const bool vec_ok = ((d.ldx & 3) == 0) && ((d.cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.x) & (x_bf16 ? 7 : 15)) == 0);
+  const bool win2 = WIN2 && vec_ok && win_rows * GPR <= PF * 256;  // else: one window, staged synchronously
   const ET* __restrict__ W = reinterpret_cast<const ET*>(d.w);
   const int n_chunks = (d.cin_pad + BK - 1) / BK;
   const int total_steps = n_chunks * d.taps;
@@ -139,6 +147,68 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
       }
   };
 
+  uint4 pre[WIN2 ? PF : 1];
+  auto win_decode = [&](int e, int c0, int& wr, int& c4, bool& ok, size_t& goff) __attribute__((always_inline)) {
+    wr = e / GPR;
+    c4 = (e % GPR) * 4;
+    const int gr = row_first + wr;
+    ok = gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c4) < d.cin;
+    const int grc = gr < tile.seq_begin ? tile.seq_begin : (gr >= tile.seq_end ? tile.seq_end - 1 : gr);
+    const int cc = (c0 + c4) < d.cin ? (c0 + c4) : d.cin - 4;
+    goff = (size_t)grc * d.ldx + cc;
+  };
+  auto win_request = [&](int c0) __attribute__((always_inline)) {
+    if constexpr (WIN2) {
+      const int total = win_rows * GPR;
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        int e = tid + q * 256;
+        e = e < total ? e : total - 1;  // clamped duplicate: unconditional loads, nothing is written for it
+        int wr, c4;
+        bool ok;
+        size_t goff;
+        win_decode(e, c0, wr, c4, ok, goff);
+        if (x_bf16) {
+          const uint2 raw = *reinterpret_cast<const uint2*>(xh + goff);
+          pre[q] = make_uint4(raw.x, raw.y, 0, 0);
+        } else {
+          pre[q] = *reinterpret_cast<const uint4*>(d.x + goff);
+        }
+      }
+    }
+  };
+  auto win_commit = [&](int c0, ET* xs) __attribute__((always_inline)) {
+    if constexpr (WIN2) {
+      const int total = win_rows * GPR;
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int e = tid + q * 256;
+        if (e < total) {
+          int wr, c4;
+          bool ok;
+          size_t goff;
+          win_decode(e, c0, wr, c4, ok, goff);
+          float4 v;
+          if (x_bf16)
+            v = make_float4(bf16_to_f32(pre[q].x & 0xFFFF), bf16_to_f32(pre[q].x >> 16), bf16_to_f32(pre[q].y & 0xFFFF), bf16_to_f32(pre[q].y >> 16));
+          else
+            v = make_float4(__builtin_bit_cast(float, pre[q].x), __builtin_bit_cast(float, pre[q].y), __builtin_bit_cast(float, pre[q].z),
+                            __builtin_bit_cast(float, pre[q].w));
+          if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          ET* dst = xs + wr * XP + c4;
+          dst[0] = Elem<BF16>::cvt(pre_activation(v.x, d.pre_act, d.pre_slope));
+          dst[1] = Elem<BF16>::cvt(pre_activation(v.y, d.pre_act, d.pre_slope));
+          dst[2] = Elem<BF16>::cvt(pre_activation(v.z, d.pre_act, d.pre_slope));
+          dst[3] = Elem<BF16>::cvt(pre_activation(v.w, d.pre_act, d.pre_slope));
+        }
+      }
+    }
+  };
+  if (win2) {  // window of slab 0: requested and committed up front
+    win_request(0);
+    win_commit(0, xs0);
+  }
+
   {
     const int k0 = d.cin_pad < BK ? d.cin_pad : BK;
     load_slab(0, 0, k0);
@@ -149,9 +219,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   for (int ch = 0; ch < n_chunks; ++ch) {
     const int c0 = ch * BK;
     const int kchunk = (d.cin_pad - c0) < BK ? (d.cin_pad - c0) : BK;
-    if (ch > 0) __syncthreads();  // the previous slab's MFMAs are done with xs
+    ET* xs = xs0 + ((win2 && (ch & 1)) ? xs_elems : 0);
+    if (!win2 && ch > 0) __syncthreads();  // the previous slab's MFMAs are done with xs
     // ---- stage the activation window: win_rows x kchunk channels, through the input activation ----
-    if (SNAKE) {
+    if (win2) {
+      // already in LDS (committed at the end of the previous slab); request the next one now, it lands under this slab's MFMAs
+      if (ch + 1 < n_chunks) win_request(c0 + BK);
+    } else if (SNAKE) {
       // anti-aliased snake computed while staging: item = (8 window rows, channel); the activated tensor never reaches HBM
       float f[12];
 #pragma unroll
@@ -277,6 +351,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
       }
       if (more) store_slab((step + 1) & 1);
     }
+    // the other window buffer was last read one slab ago and every wave has passed a barrier since: safe to overwrite;
+    // the first barrier of the next slab publishes it
+    if (win2 && ch + 1 < n_chunks) win_commit(c0 + BK, xs0 + ((ch & 1) ? 0 : xs_elems));
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
@@ -372,12 +449,16 @@ static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   const int n_tiles_n = ((DUAL ? d.half_pad : d.wn) + C::BN - 1) / C::BN;
   dim3 grid(d.n_tiles, n_tiles_n), block(256);
   const size_t xs_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7;
-  const size_t lds = (xs_elems + (size_t)2 * NH * BK * C::BN) * ESZ;
+  const size_t lds = ((C::BM == 64 && !SNAKE ? 2 : 1) * xs_elems + (size_t)2 * NH * BK * C::BN) * ESZ;
   TTS_CHECK_ARG(lds <= 160 * 1024, "conv1d: LDS %zu B exceeds 160 KiB (taps %d dil %d)", lds, d.taps, d.dil);
   auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE>;
   static bool lds_raised = false;  // once per instantiation (also keeps the call out of stream captures)
   if (lds > 64 * 1024 && !lds_raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      set_error("conv1d: raising the dynamic LDS limit failed: %s", hipGetErrorString(e));
+      return TTS_E_LAUNCH;
+    }
     lds_raised = true;
   }
   hipLaunchKernelGGL(k, grid, block, lds, st, d);

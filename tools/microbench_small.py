@@ -1,0 +1,43 @@
+"""Batch-1 conv shapes of the acoustic model, launched back to back (warm instruction cache, warm L2) - compare with the
+in-pipeline durations of the same launches in a kernel trace to separate cold-start cost from steady-state cost."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import ims_toucan_prosody_variance_amd  # noqa: F401
+from ims_toucan_prosody_variance_amd import capi, engine, packing
+from ims_toucan_prosody_variance_amd.ragged import Ragged
+
+
+def main():
+    dev = torch.device("cuda:0")
+    ops = engine.Ops(dev)
+    shapes = [("WN gated k5", 320, 192, 384, 5, capi.MODE_GATED), ("FFN2 dec", 640, 1536, 192, 1, capi.MODE_LINEAR),
+              ("FFN1 dec", 640, 192, 1536, 1, capi.MODE_LINEAR), ("qkv dec", 640, 192, 576, 1, capi.MODE_LINEAR),
+              ("FFN2 enc", 128, 1536, 192, 1, capi.MODE_LINEAR), ("out enc", 128, 192, 192, 1, capi.MODE_LINEAR)]
+    for name, M, cin, cout, k, mode in shapes:
+        rs = np.random.RandomState(0)
+        cw = packing.pack_conv((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32), np.zeros(cout, np.float32), dev, mode=mode, bf16=True)
+        rag = Ragged([M], dev)
+        x = torch.randn(rag.total_rows, cin, device=dev)
+        y = torch.empty(rag.total_rows, cout // 2 if mode != capi.MODE_LINEAR else cout, device=dev)
+        for comp, cname in ((capi.COMPUTE_F32, "f32"), (capi.COMPUTE_BF16, "bf16")):
+            for split in (0,):
+                run = lambda: ops.conv(cw, x, y, rag, compute=comp)
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"{name:12s} M={M:4d} {cin:4d}->{cout:4d} k={k} {cname:5s}: {1e3 * e0.elapsed_time(e1) / 50:7.1f} us / launch", flush=True)
+
+
+if __name__ == "__main__":
+    main()
