@@ -89,6 +89,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
+ABI_VERSION = 4  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):
@@ -116,6 +117,10 @@ def lib():
             raise ToucanHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    got = handle.tts_abi_version()
+    if got != ABI_VERSION:
+        raise ToucanHipError(f"{LIB_PATH} reports ABI version {got}, this binding was written for {ABI_VERSION}: rebuild the "
+                             f"library (python -c 'import __graft_entry__ as g; g.build()')")
     _LIB = handle
     return handle
 

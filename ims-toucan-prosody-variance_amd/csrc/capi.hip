@@ -51,7 +51,7 @@ int resblock_tile_rows(int c);
 extern "C" {
 
 const char* tts_last_error(void) { return tts::g_err; }
-int tts_abi_version(void) { return 1; }
+int tts_abi_version(void) { return TTS_ABI_VERSION; }
 
 int tts_conv1d_tile_rows(int32_t cout, int32_t mode) { return tts::conv1d_tile_rows(cout, mode); }
 int tts_conv1d_n_tile(int32_t cout, int32_t mode) { return tts::conv1d_n_tile(cout, mode); }

@@ -204,6 +204,9 @@ int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float*
                     int32_t c, tts_stream_t stream);
 
 const char* tts_last_error(void);
+/* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
+ * another value (the descriptors are passed by layout, a stale build would read garbage). */
+#define TTS_ABI_VERSION 4
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -102,7 +102,7 @@ class Emulator:
         return self._err
 
     def tts_abi_version(self):
-        return 1
+        return capi.ABI_VERSION
 
     def tts_conv1d_tile_rows(self, cout, mode):
         return self._reallib().tts_conv1d_tile_rows(cout, mode)
