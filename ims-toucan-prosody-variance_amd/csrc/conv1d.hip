@@ -34,6 +34,22 @@ __device__ __forceinline__ float pre_activation(float v, int pre_act, float slop
 
 __device__ __forceinline__ unsigned short f2bf(float f) { return f32_to_bf16(f); }
 
+// One 4-channel group into the LDS window: the bf16 window takes it as ONE 8-byte store (rows are 16-byte aligned and the group
+// starts at a multiple of 4 channels) - four 2-byte stores per group made the staging pass as long as the MFMAs it feeds.
+template <bool BF16, class T>
+__device__ __forceinline__ void store_group(T* dst, float a, float b, float c, float e) {
+  if constexpr (BF16) {
+    const unsigned int lo = (unsigned int)f32_to_bf16(a) | ((unsigned int)f32_to_bf16(b) << 16);
+    const unsigned int hi = (unsigned int)f32_to_bf16(c) | ((unsigned int)f32_to_bf16(e) << 16);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+  } else {
+    dst[0] = a;
+    dst[1] = b;
+    dst[2] = c;
+    dst[3] = e;
+  }
+}
+
 template <bool BF16>
 struct Elem;
 template <>
@@ -157,23 +173,30 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
     const int cc = (c0 + c4) < d.cin ? (c0 + c4) : d.cin - 4;
     goff = (size_t)grc * d.ldx + cc;
   };
+  // (the input-dtype test stays OUTSIDE the load loops: inside, the compiler if-converts it into "issue both loads, wait, select"
+  //  per group and the requests serialise - measured ~1100 cycles per slab for five loads)
   auto win_request = [&](int c0) __attribute__((always_inline)) {
     if constexpr (WIN2) {
       const int total = win_rows * GPR;
+      size_t goff[PF];
 #pragma unroll
       for (int q = 0; q < PF; ++q) {
         int e = tid + q * 256;
         e = e < total ? e : total - 1;  // clamped duplicate: unconditional loads, nothing is written for it
         int wr, c4;
         bool ok;
-        size_t goff;
-        win_decode(e, c0, wr, c4, ok, goff);
-        if (x_bf16) {
-          const uint2 raw = *reinterpret_cast<const uint2*>(xh + goff);
-          pre[q] = make_uint4(raw.x, raw.y, 0, 0);
-        } else {
-          pre[q] = *reinterpret_cast<const uint4*>(d.x + goff);
+        win_decode(e, c0, wr, c4, ok, goff[q]);
+      }
+      if (x_bf16) {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+          const uint2 raw = *reinterpret_cast<const uint2*>(xh + goff[q]);
+          pre[q].x = raw.x;
+          pre[q].y = raw.y;
         }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PF; ++q) pre[q] = *reinterpret_cast<const uint4*>(d.x + goff[q]);
       }
     }
   };
@@ -196,10 +219,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
                             __builtin_bit_cast(float, pre[q].w));
           if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
           ET* dst = xs + wr * XP + c4;
-          dst[0] = Elem<BF16>::cvt(pre_activation(v.x, d.pre_act, d.pre_slope));
-          dst[1] = Elem<BF16>::cvt(pre_activation(v.y, d.pre_act, d.pre_slope));
-          dst[2] = Elem<BF16>::cvt(pre_activation(v.z, d.pre_act, d.pre_slope));
-          dst[3] = Elem<BF16>::cvt(pre_activation(v.w, d.pre_act, d.pre_slope));
+          store_group<BF16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
+                            pre_activation(v.z, d.pre_act, d.pre_slope), pre_activation(v.w, d.pre_act, d.pre_slope));
         }
       }
     }
@@ -257,34 +278,46 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
       const int q4 = kchunk >> 2;  // float4 groups per row
       const int total = win_rows * q4;
       for (int base = tid; base < total; base += 256 * PER) {
-        float4 v[PER];
+        uint4 raw[PER];
+        size_t goff[PER];
+        bool okv[PER];
 #pragma unroll
         for (int p = 0; p < PER; ++p) {
           int e = base + p * 256;
           e = e < total ? e : total - 1;  // tail duplicates the last element (same value, benign)
           const int wr = e / q4, c4 = (e % q4) * 4;
           const int gr = row_first + wr;
-          const bool ok = gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c4) < d.cin;
+          okv[p] = gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c4) < d.cin;
           const int grc = gr < tile.seq_begin ? tile.seq_begin : (gr >= tile.seq_end ? tile.seq_end - 1 : gr);
           const int cc = (c0 + c4) < d.cin ? (c0 + c4) : d.cin - 4;
-          if (x_bf16) {  // 4 bf16 = 8 bytes
-            const uint2 raw = *reinterpret_cast<const uint2*>(xh + (size_t)grc * d.ldx + cc);
-            v[p] = make_float4(bf16_to_f32(raw.x & 0xFFFF), bf16_to_f32(raw.x >> 16), bf16_to_f32(raw.y & 0xFFFF), bf16_to_f32(raw.y >> 16));
-          } else {
-            v[p] = *reinterpret_cast<const float4*>(d.x + (size_t)grc * d.ldx + cc);
+          goff[p] = (size_t)grc * d.ldx + cc;
+        }
+        if (x_bf16) {  // 4 bf16 = 8 bytes (dtype test outside the load loop, see win_request)
+#pragma unroll
+          for (int p = 0; p < PER; ++p) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(xh + goff[p]);
+            raw[p].x = r2.x;
+            raw[p].y = r2.y;
           }
-          if (!ok) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+          for (int p = 0; p < PER; ++p) raw[p] = *reinterpret_cast<const uint4*>(d.x + goff[p]);
         }
 #pragma unroll
         for (int p = 0; p < PER; ++p) {
           int e = base + p * 256;
           e = e < total ? e : total - 1;
           const int wr = e / q4, c4 = (e % q4) * 4;
+          float4 v;
+          if (x_bf16)
+            v = make_float4(bf16_to_f32(raw[p].x & 0xFFFF), bf16_to_f32(raw[p].x >> 16), bf16_to_f32(raw[p].y & 0xFFFF), bf16_to_f32(raw[p].y >> 16));
+          else
+            v = make_float4(__builtin_bit_cast(float, raw[p].x), __builtin_bit_cast(float, raw[p].y), __builtin_bit_cast(float, raw[p].z),
+                            __builtin_bit_cast(float, raw[p].w));
+          if (!okv[p]) v = make_float4(0.f, 0.f, 0.f, 0.f);
           ET* dst = xs + wr * XP + c4;
-          dst[0] = Elem<BF16>::cvt(pre_activation(v[p].x, d.pre_act, d.pre_slope));
-          dst[1] = Elem<BF16>::cvt(pre_activation(v[p].y, d.pre_act, d.pre_slope));
-          dst[2] = Elem<BF16>::cvt(pre_activation(v[p].z, d.pre_act, d.pre_slope));
-          dst[3] = Elem<BF16>::cvt(pre_activation(v[p].w, d.pre_act, d.pre_slope));
+          store_group<BF16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
+                            pre_activation(v.z, d.pre_act, d.pre_slope), pre_activation(v.w, d.pre_act, d.pre_slope));
         }
       }
     } else {
