@@ -16,6 +16,8 @@
 // consecutive rows, hits 32 distinct banks); weights [32][BN] floats (B-fragment read is a contiguous row).
 //
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
+#include <cstdlib>
+
 #include "common.h"
 #include "snake.h"
 
@@ -62,6 +64,60 @@ struct Elem<true> {
   using T = unsigned short;
   static __device__ __forceinline__ unsigned short cvt(float v) { return f2bf(v); }
 };
+
+// Fused epilogue shared by the conv kernels; C/D layout of a 32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// Wave (wm, wn) of the workgroup owns accumulator tiles [i][j] at rows tile.row0 + (wm*TM + i)*32, columns n0 + (wn*TN + j)*32.
+template <int TM, int TN, int NH, bool DUAL>
+__device__ __forceinline__ void conv_epilogue(const TtsConvDesc& d, const TtsTile& tile, int n0, int wm, int wn, int lrow, int lk,
+                                              const f32x16 (&acc)[NH][TM][TN]) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + lrow;
+      if (n >= d.cout) continue;
+      const float ba = d.bias ? d.bias[n] : 0.0f;
+      const float bg = (DUAL && d.bias) ? d.bias[d.cout + n] : 0.0f;
+      const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tile.row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (row >= tile.seq_end) continue;
+        float v = acc[0][i][j][r] + ba + sv;
+        if (d.preadd) v += d.preadd[(size_t)row * d.ld_preadd + n];
+        if (DUAL) {
+          float g = acc[NH - 1][i][j][r] + bg;
+          if (d.preadd) g += d.preadd[(size_t)row * d.ld_preadd + d.cout + n];
+          if (d.mode == TTS_MODE_GLU) {
+            v = v * (1.0f / (1.0f + expf(-g)));
+          } else if (d.mode == TTS_MODE_GATED) {
+            v = tanhf(v) * (1.0f / (1.0f + expf(-g)));
+          } else {  // COUPLING
+            v = (d.aux[(size_t)row * d.ld_aux + n] - v) * expf(-g);
+          }
+        } else {
+          if (d.act == TTS_ACT_RELU) v = fmaxf(v, 0.0f);
+          else if (d.act == TTS_ACT_TANH) v = tanhf(v);
+        }
+        v *= d.alpha;
+        if (d.res) {
+          const float rv = (d.io_flags & TTS_IO_RES_BF16) ? bf16_to_f32(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n])
+                                                          : d.res[(size_t)row * d.ld_res + n];
+          v += d.res_scale * rv;
+        }
+        if (d.io_flags & TTS_IO_Y_BF16) {
+          unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
+          if (d.accumulate) v += bf16_to_f32(*yp);
+          *yp = f32_to_bf16(v);
+        } else {
+          float* yp = d.y + (size_t)row * d.ldy + n;
+          if (d.accumulate) v += *yp;
+          *yp = v;
+        }
+      }
+    }
+  }
+}
 
 // Main loop (both precisions): steps s = (channel slab, tap).  The weight slab of step s+1 is fetched into
 // registers right after the barrier that opens step s and written to the other LDS buffer after the MFMAs of
@@ -389,54 +445,121 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
     if (win2 && ch + 1 < n_chunks) win_commit(c0 + BK, xs0 + ((ch & 1) ? 0 : xs_elems));
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+  conv_epilogue<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1-tap convs (linears) in the small-batch form without LDS: every wavefront streams its own A rows and B columns straight
+// from global memory / L2 into registers, DEPTH k-steps ahead, and never meets a barrier.  With a single tap there is no
+// window to share between taps, and at 1-4 workgroups per CU the LDS-staged loop above is a chain of exposed round trips
+// (barrier, slab load, window load: ~1.6 us per 64-channel step whatever the MFMA work).  Same 64 x 64 workgroup tile and
+// wave layout as the small form, same packed weights, same epilogue.
+//   bf16: A fragment = 8 consecutive channels of the lane's row (two 16-byte loads of fp32, or one of bf16, converted in
+//         registers), B fragment = one 16-byte load from the [cin/8][wn][8] packing.
+//   fp32: v_mfma_f32_32x32x2_f32 takes k = lane>>5 of a k-pair; the k order inside a group of 8 channels is permuted so that
+//         one float4 of A per lane feeds four MFMAs (MFMA j of group g contracts channels 8g + j and 8g + 4 + j).
+// ------------------------------------------------------------------------------------------------
+template <bool DUAL, bool BF16, bool XB>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
+  constexpr int NH = DUAL ? 2 : 1;
+  constexpr int DEPTH = 4;  // k-steps (bf16: 16 channels, fp32: 8 channels) in flight per wavefront
+  const TtsTile tile = d.tiles[blockIdx.x];
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, lrow = lane & 31, lk = lane >> 5;
+  int row = tile.row0 + wm * 32 + lrow;
+  row = row < tile.seq_end ? row : tile.seq_end - 1;  // rows past the utterance load a valid row, the epilogue drops them
+  const int col = n0 + wn * 32 + lrow;
+
+  f32x16 acc[NH][1][1];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 32 + j * 32 + lrow;
-      if (n >= d.cout) continue;
-      const float ba = d.bias ? d.bias[n] : 0.0f;
-      const float bg = (DUAL && d.bias) ? d.bias[d.cout + n] : 0.0f;
-      const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n] : 0.0f;
+    for (int r = 0; r < 16; ++r) acc[h][0][0][r] = 0.0f;
+
+  // Buffer loads (resource descriptor + 32-bit byte offset): one instruction per 16-byte fragment whatever the optimiser would
+  // make of a plain vector load (it splits a uint4 whose lanes are consumed one by one into four dword loads), and no 64-bit
+  // address arithmetic in the stream.  The tensors of this path are far below 2 GiB.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w), 0, 0x7FFFFFFF, 0x00020000);
+  if constexpr (BF16) {
+    const int n_steps = d.cin_pad >> 4;  // multiple of DEPTH (dispatch guarantees cin % 64 == 0)
+    // byte offsets: A = row * ldx + lk * 8 channels (fp32: 4 B, bf16: 2 B each), 16 channels per k-step;
+    //               B = ((2 ks + lk) * wn + col) * 16 in the [cin/8][wn][8] packing (+ half_pad * 16 for the gate half)
+    const unsigned int xoff = (unsigned int)((size_t)row * d.ldx + lk * 8) * (XB ? 2u : 4u);
+    const unsigned int xstep = XB ? 32u : 64u;
+    const unsigned int woff = (unsigned int)(lk * d.wn + col) * 16u, wstep = (unsigned int)d.wn * 32u, whalf = (unsigned int)d.half_pad * 16u;
+    u32x4 a0[DEPTH], a1[DEPTH], b[NH][DEPTH];
+    auto request = [&](int slot, int ks) __attribute__((always_inline)) {
+      a0[slot] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, ks * xstep, 0);
+      if constexpr (!XB) a1[slot] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff + 16, ks * xstep, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = tile.row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= tile.seq_end) continue;
-        float v = acc[0][i][j][r] + ba + sv;
-        if (d.preadd) v += d.preadd[(size_t)row * d.ld_preadd + n];
-        if (DUAL) {
-          float g = acc[NH - 1][i][j][r] + bg;
-          if (d.preadd) g += d.preadd[(size_t)row * d.ld_preadd + d.cout + n];
-          if (d.mode == TTS_MODE_GLU) {
-            v = v * (1.0f / (1.0f + expf(-g)));
-          } else if (d.mode == TTS_MODE_GATED) {
-            v = tanhf(v) * (1.0f / (1.0f + expf(-g)));
-          } else {  // COUPLING
-            v = (d.aux[(size_t)row * d.ld_aux + n] - v) * expf(-g);
+      for (int h = 0; h < NH; ++h) b[h][slot] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + h * whalf, ks * wstep, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) request(u, u);
+    for (int base = 0; base < n_steps; base += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        u32x4 ap;  // 8 bf16 channels of this lane's row
+        if constexpr (XB) {
+          ap = a0[u];
+          if (d.pre_act == TTS_PRE_LRELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              ap[q] = (unsigned int)f32_to_bf16(pre_activation(bf16_to_f32(a0[u][q] & 0xFFFF), d.pre_act, d.pre_slope)) |
+                      ((unsigned int)f32_to_bf16(pre_activation(bf16_to_f32(a0[u][q] >> 16), d.pre_act, d.pre_slope)) << 16);
           }
         } else {
-          if (d.act == TTS_ACT_RELU) v = fmaxf(v, 0.0f);
-          else if (d.act == TTS_ACT_TANH) v = tanhf(v);
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            ap[q] = (unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a0[u][2 * q]), d.pre_act, d.pre_slope)) |
+                    ((unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a0[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
+            ap[2 + q] = (unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a1[u][2 * q]), d.pre_act, d.pre_slope)) |
+                        ((unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a1[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
+          }
         }
-        v *= d.alpha;
-        if (d.res) {
-          const float rv = (d.io_flags & TTS_IO_RES_BF16) ? bf16_to_f32(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n])
-                                                          : d.res[(size_t)row * d.ld_res + n];
-          v += d.res_scale * rv;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+          acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, b[h][u]), acc[h][0][0], 0, 0, 0);
+        int nxt = base + u + DEPTH;
+        nxt = nxt < n_steps ? nxt : n_steps - 1;  // the tail re-requests the last step (unused): no branch in the stream
+        request(u, nxt);
+      }
+    }
+  } else {
+    const int n_groups = d.cin_pad >> 3;  // groups of 8 channels; multiple of DEPTH (cin % 32 == 0)
+    // A = row * ldx + 8 g + 4 lk (float4); B row (8 g + 4 lk + j) of the [cin][wn] fp32 weights, column col
+    const unsigned int xoff = (unsigned int)((size_t)row * d.ldx + lk * 4) * 4u;
+    const unsigned int woff = (unsigned int)((size_t)(lk * 4) * d.wn + col) * 4u, wrow = (unsigned int)d.wn * 4u, whalf = (unsigned int)d.half_pad * 4u;
+    u32x4 a[DEPTH];
+    unsigned int b[NH][DEPTH][4];
+    auto request = [&](int slot, int g) __attribute__((always_inline)) {
+      a[slot] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, g * 32, 0);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[h][slot][j] = __builtin_amdgcn_raw_buffer_load_b32(wr, woff + j * wrow + h * whalf, g * 8 * wrow, 0);
+    };
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) request(u, u);
+    for (int base = 0; base < n_groups; base += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float av = pre_activation(__builtin_bit_cast(float, a[u][j]), d.pre_act, d.pre_slope);
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __builtin_bit_cast(float, b[h][u][j]), acc[h][0][0], 0, 0, 0);
         }
-        if (d.io_flags & TTS_IO_Y_BF16) {
-          unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
-          if (d.accumulate) v += bf16_to_f32(*yp);
-          *yp = f32_to_bf16(v);
-        } else {
-          float* yp = d.y + (size_t)row * d.ldy + n;
-          if (d.accumulate) v += *yp;
-          *yp = v;
-        }
+        int nxt = base + u + DEPTH;
+        nxt = nxt < n_groups ? nxt : n_groups - 1;
+        request(u, nxt);
       }
     }
   }
+  conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,6 +634,39 @@ static int launch_cfg(const TtsConvDesc& d, hipStream_t st) {
   return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, false>(d, st);
 }
 
+// the LDS-free 1-tap path: single tap, no padding, whole 64-channel (bf16) / 32-channel (fp32) slabs, 16-byte aligned rows
+static bool gemm_rows_ok(const TtsConvDesc& d) {
+  if (d.taps != 1 || d.pad_left != 0 || d.pre_act == TTS_PRE_SNAKE || d.cin != d.cin_pad) return false;
+  const bool xb = d.io_flags & TTS_IO_X_BF16;
+  if (xb && d.compute == 0) return false;
+  if (d.cin % (d.compute ? 64 : 32) != 0) return false;
+  // bf16: measured on MI355X the LDS-staged form is as fast for short rows (K = 192: 10.9 vs 11.0 us) and much faster for long
+  // ones (K = 1536, M = 640: 39 vs 139 us - 32 lanes of one load touch 32 rows 6 KB apart, which lands on two L2 channels), so
+  // bf16 keeps it unless asked; fp32 gains 25-30 % (15.5 -> 11.5 us, 78 -> 54 us): its MFMAs are 8x longer per byte loaded.
+  if (d.compute != 0 && std::getenv("TOUCAN_GEMM_ROWS_BF16") == nullptr) return false;
+  if ((d.ldx & (xb ? 7 : 3)) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0) return false;
+  return std::getenv("TOUCAN_NO_GEMM_ROWS") == nullptr;  // escape hatch for A/B measurements
+}
+
+static int launch_gemm_rows(const TtsConvDesc& d, hipStream_t st) {
+  const bool dual = d.mode != TTS_MODE_LINEAR, xb = d.io_flags & TTS_IO_X_BF16;
+  const int cols = dual ? d.half_pad : d.wn;
+  dim3 grid(d.n_tiles, cols / 64), block(256);
+#define TTS_GEMM_ROWS(DUAL_, BF16_, XB_) hipLaunchKernelGGL((gemm_rows_kernel<DUAL_, BF16_, XB_>), grid, block, 0, st, d)
+  if (d.compute == 0) {
+    if (dual) TTS_GEMM_ROWS(true, false, false);
+    else TTS_GEMM_ROWS(false, false, false);
+  } else if (xb) {
+    if (dual) TTS_GEMM_ROWS(true, true, true);
+    else TTS_GEMM_ROWS(false, true, true);
+  } else {
+    if (dual) TTS_GEMM_ROWS(true, true, false);
+    else TTS_GEMM_ROWS(false, true, false);
+  }
+#undef TTS_GEMM_ROWS
+  return launch_status("conv1d (1-tap rows)");
+}
+
 int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.x && d.w && d.y && d.tiles, "conv1d: null pointer");
   TTS_CHECK_ARG(d.cin > 0 && d.cout > 0 && d.taps > 0 && d.dil > 0, "conv1d: bad dims");
@@ -527,6 +683,7 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.tile_rows == bm, "conv1d: tile table built for %d rows, kernel needs %d", d.tile_rows, bm);
   TTS_CHECK_ARG(cols % bn == 0 && cols >= d.cout, "conv1d: packed width %d not a multiple of the N tile %d (cout %d)", cols, bn, d.cout);
   TTS_CHECK_ARG(d.mode == TTS_MODE_LINEAR || d.wn == 2 * d.half_pad, "conv1d: dual mode needs wn == 2*half_pad");
+  if ((s == S_64x64 || s == S_D64x64) && gemm_rows_ok(d)) return launch_gemm_rows(d, st);
   switch (s) {
     case S_128x128: return launch_cfg<2, 2, 2, 2, false>(d, st);
     case S_128x96: return launch_cfg<1, 3, 4, 1, false>(d, st);
