@@ -476,31 +476,46 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[h][0][0][r] = 0.0f;
 
-  // Buffer loads (resource descriptor + 32-bit byte offset): one instruction per 16-byte fragment whatever the optimiser would
-  // make of a plain vector load (it splits a uint4 whose lanes are consumed one by one into four dword loads), and no 64-bit
-  // address arithmetic in the stream.  The tensors of this path are far below 2 GiB.
+  // The operand stream is written with inline-asm loads and hand-counted waits: the loads return in order, so before k-step s
+  // is consumed exactly (DEPTH-1) * L younger loads may stay in flight (L = loads per k-step).  Left to the compiler the same
+  // loop either had its 16-byte loads split into dwords (the fragments are consumed lane-element by lane-element) or drained
+  // every outstanding load at the loop head (it cannot count across the back edge); the asm is invisible to its counters, and
+  // each wait is followed by empty asm statements that "redefine" the registers just waited for, so no use can move above it.
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7FFFFFFF, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w), 0, 0x7FFFFFFF, 0x00020000);
+  // (by value: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0 whatever the index)
+  auto u2f = [](unsigned int bits) __attribute__((always_inline)) { return __builtin_bit_cast(float, bits); };
+#define TTS_GLOAD128(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define TTS_GLOAD32(dst_, ptr_) asm volatile("global_load_dword %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define TTS_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define TTS_PIN(r_) asm volatile("" : "+v"(r_))
   if constexpr (BF16) {
     const int n_steps = d.cin_pad >> 4;  // multiple of DEPTH (dispatch guarantees cin % 64 == 0)
-    // byte offsets: A = row * ldx + lk * 8 channels (fp32: 4 B, bf16: 2 B each), 16 channels per k-step;
-    //               B = ((2 ks + lk) * wn + col) * 16 in the [cin/8][wn][8] packing (+ half_pad * 16 for the gate half)
-    const unsigned int xoff = (unsigned int)((size_t)row * d.ldx + lk * 8) * (XB ? 2u : 4u);
-    const unsigned int xstep = XB ? 32u : 64u;
-    const unsigned int woff = (unsigned int)(lk * d.wn + col) * 16u, wstep = (unsigned int)d.wn * 32u, whalf = (unsigned int)d.half_pad * 16u;
+    constexpr int L = (XB ? 1 : 2) + NH;
+    // A: 8 channels of this lane's row per k-step (fp32: two 16-byte loads, bf16: one); B: one 16-byte unit of [cin/8][wn][8]
+    const char* xp = reinterpret_cast<const char*>(d.x) + ((size_t)row * d.ldx + lk * 8) * (XB ? 2 : 4);
+    const size_t xstep = XB ? 32 : 64;
+    const char* wp = reinterpret_cast<const char*>(d.w) + ((size_t)lk * d.wn + col) * 16;
+    const size_t wstep = (size_t)d.wn * 32, whalf = (size_t)d.half_pad * 16;
     u32x4 a0[DEPTH], a1[DEPTH], b[NH][DEPTH];
     auto request = [&](int slot, int ks) __attribute__((always_inline)) {
-      a0[slot] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, ks * xstep, 0);
-      if constexpr (!XB) a1[slot] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff + 16, ks * xstep, 0);
+      TTS_GLOAD128(a0[slot], xp + ks * xstep);
+      if constexpr (!XB) TTS_GLOAD128(a1[slot], xp + ks * xstep + 16);
 #pragma unroll
-      for (int h = 0; h < NH; ++h) b[h][slot] = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + h * whalf, ks * wstep, 0);
+      for (int h = 0; h < NH; ++h) TTS_GLOAD128(b[h][slot], wp + ks * wstep + h * whalf);
+    };
+    auto arrive = [&](int slot) __attribute__((always_inline)) {
+      TTS_WAIT_VM((DEPTH - 1) * L);
+      TTS_PIN(a0[slot]);
+      if constexpr (!XB) TTS_PIN(a1[slot]);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) TTS_PIN(b[h][slot]);
     };
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) request(u, u);
     for (int base = 0; base < n_steps; base += DEPTH) {
 #pragma unroll
       for (int u = 0; u < DEPTH; ++u) {
+        arrive(u);
         u32x4 ap;  // 8 bf16 channels of this lane's row
         if constexpr (XB) {
           ap = a0[u];
@@ -513,52 +528,91 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
         } else {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            ap[q] = (unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a0[u][2 * q]), d.pre_act, d.pre_slope)) |
-                    ((unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a0[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
-            ap[2 + q] = (unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a1[u][2 * q]), d.pre_act, d.pre_slope)) |
-                        ((unsigned int)f32_to_bf16(pre_activation(__builtin_bit_cast(float, a1[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
+            ap[q] = (unsigned int)f32_to_bf16(pre_activation(u2f(a0[u][2 * q]), d.pre_act, d.pre_slope)) |
+                    ((unsigned int)f32_to_bf16(pre_activation(u2f(a0[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
+            ap[2 + q] = (unsigned int)f32_to_bf16(pre_activation(u2f(a1[u][2 * q]), d.pre_act, d.pre_slope)) |
+                        ((unsigned int)f32_to_bf16(pre_activation(u2f(a1[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
           }
         }
+        u32x4 bf[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bf[h] = b[h][u];  // copies: the slot is re-requested below while the MFMA may still read
 #pragma unroll
         for (int h = 0; h < NH; ++h)
-          acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, b[h][u]), acc[h][0][0], 0, 0, 0);
+          acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, bf[h]), acc[h][0][0], 0, 0, 0);
         int nxt = base + u + DEPTH;
         nxt = nxt < n_steps ? nxt : n_steps - 1;  // the tail re-requests the last step (unused): no branch in the stream
         request(u, nxt);
       }
     }
+    TTS_WAIT_VM(0);  // drain the tail requests: their destination registers stay allocated (pinned) until here
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      TTS_PIN(a0[u]);
+      if constexpr (!XB) TTS_PIN(a1[u]);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) TTS_PIN(b[h][u]);
+    }
   } else {
     const int n_groups = d.cin_pad >> 3;  // groups of 8 channels; multiple of DEPTH (cin % 32 == 0)
-    // A = row * ldx + 8 g + 4 lk (float4); B row (8 g + 4 lk + j) of the [cin][wn] fp32 weights, column col
-    const unsigned int xoff = (unsigned int)((size_t)row * d.ldx + lk * 4) * 4u;
-    const unsigned int woff = (unsigned int)((size_t)(lk * 4) * d.wn + col) * 4u, wrow = (unsigned int)d.wn * 4u, whalf = (unsigned int)d.half_pad * 4u;
+    constexpr int L = 1 + 4 * NH;
+    // A: float4 at channels 8 g + 4 lk; B: rows 8 g + 4 lk + j of the [cin][wn] fp32 weights, column col
+    const char* xp = reinterpret_cast<const char*>(d.x) + ((size_t)row * d.ldx + lk * 4) * 4;
+    const char* wp = reinterpret_cast<const char*>(d.w) + ((size_t)(lk * 4) * d.wn + col) * 4;
+    const size_t wrow = (size_t)d.wn * 4, whalf = (size_t)d.half_pad * 4;
     u32x4 a[DEPTH];
     unsigned int b[NH][DEPTH][4];
     auto request = [&](int slot, int g) __attribute__((always_inline)) {
-      a[slot] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff, g * 32, 0);
+      TTS_GLOAD128(a[slot], xp + (size_t)g * 32);
 #pragma unroll
       for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[h][slot][j] = __builtin_amdgcn_raw_buffer_load_b32(wr, woff + j * wrow + h * whalf, g * 8 * wrow, 0);
+        for (int j = 0; j < 4; ++j) TTS_GLOAD32(b[h][slot][j], wp + ((size_t)g * 8 + j) * wrow + h * whalf);
+    };
+    auto arrive = [&](int slot) __attribute__((always_inline)) {
+      TTS_WAIT_VM((DEPTH - 1) * L);
+      TTS_PIN(a[slot]);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) TTS_PIN(b[h][slot][j]);
     };
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) request(u, u);
     for (int base = 0; base < n_groups; base += DEPTH) {
 #pragma unroll
       for (int u = 0; u < DEPTH; ++u) {
+        arrive(u);
+        float av[4], bv[NH][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float av = pre_activation(__builtin_bit_cast(float, a[u][j]), d.pre_act, d.pre_slope);
+          av[j] = pre_activation(u2f(a[u][j]), d.pre_act, d.pre_slope);
 #pragma unroll
-          for (int h = 0; h < NH; ++h)
-            acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, __builtin_bit_cast(float, b[h][u][j]), acc[h][0][0], 0, 0, 0);
+          for (int h = 0; h < NH; ++h) bv[h][j] = u2f(b[h][u][j]);
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[h][j], acc[h][0][0], 0, 0, 0);
         int nxt = base + u + DEPTH;
         nxt = nxt < n_groups ? nxt : n_groups - 1;
         request(u, nxt);
       }
     }
+    TTS_WAIT_VM(0);
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      TTS_PIN(a[u]);
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) TTS_PIN(b[h][u][j]);
+    }
   }
+#undef TTS_GLOAD128
+#undef TTS_GLOAD32
+#undef TTS_WAIT_VM
+#undef TTS_PIN
   conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
 }
 
@@ -640,10 +694,14 @@ static bool gemm_rows_ok(const TtsConvDesc& d) {
   const bool xb = d.io_flags & TTS_IO_X_BF16;
   if (xb && d.compute == 0) return false;
   if (d.cin % (d.compute ? 64 : 32) != 0) return false;
-  // bf16: measured on MI355X the LDS-staged form is as fast for short rows (K = 192: 10.9 vs 11.0 us) and much faster for long
-  // ones (K = 1536, M = 640: 39 vs 139 us - 32 lanes of one load touch 32 rows 6 KB apart, which lands on two L2 channels), so
-  // bf16 keeps it unless asked; fp32 gains 25-30 % (15.5 -> 11.5 us, 78 -> 54 us): its MFMAs are 8x longer per byte loaded.
-  if (d.compute != 0 && std::getenv("TOUCAN_GEMM_ROWS_BF16") == nullptr) return false;
+  // Measured on MI355X (tools/microbench_small.py): fp32 gains 25-40 % at every size (K = 192: 15.5 -> 11.5 us, K = 1536:
+  // 78 -> 48 us; its MFMAs are 8x longer per byte loaded).  bf16 gains at latency-bound grid sizes (K = 1536, 30 workgroups:
+  // 39 -> 29 us; K = 192: 11.5 -> 9.5 us) and is neutral once the grid fills the chip, where the LDS-staged form shares each
+  // operand between two wavefronts - so bf16 takes this path for grids up to two workgroups per CU only.
+  if (d.compute != 0 && std::getenv("TOUCAN_GEMM_ROWS_BF16") == nullptr) {
+    const int cols = d.mode != TTS_MODE_LINEAR ? d.half_pad : d.wn;
+    if ((long long)d.n_tiles * (cols / 64) > 512) return false;
+  }
   if ((d.ldx & (xb ? 7 : 3)) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0) return false;
   return std::getenv("TOUCAN_NO_GEMM_ROWS") == nullptr;  // escape hatch for A/B measurements
 }

@@ -328,3 +328,43 @@ def test_library_rejects_bad_arguments(gpu):
     cw.tile_rows = 64  # tile table built for the wrong tile height
     with pytest.raises(capi.ToucanHipError, match="tile table"):
         gpu.conv(cw, gpu.empty(10, 32), gpu.empty(10, 32), rag)
+
+
+@pytest.mark.parametrize("cin,cout,mode,lengths", [
+    (64, 192, capi.MODE_LINEAR, [1, 1, 1, 1, 1]),       # one row per utterance (the conditional-layer-norm MLPs)
+    (192, 192, capi.MODE_LINEAR, [7]),
+    (1536, 192, capi.MODE_LINEAR, [130]),
+    (192, 576, capi.MODE_LINEAR, [97, 5]),
+    (256, 256, capi.MODE_LINEAR, [1, 1, 1]),
+    (192, 384, capi.MODE_GLU, [33, 128]),
+    (192, 1536, capi.MODE_LINEAR, [64, 65]),
+])
+@pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
+def test_conv1d_one_tap_rows_kernel(gpu, cpu, cin, cout, mode, lengths, compute, monkeypatch):
+    """1-tap convs with 16-byte aligned contiguous rows take the LDS-free kernel in the small-batch form (fp32 by default, bf16 when
+    TOUCAN_GEMM_ROWS_BF16 is set); every epilogue feature, against the emulator."""
+    monkeypatch.setenv("TOUCAN_GEMM_ROWS_BF16", "1")
+    w = rnd(cout, cin, 1, seed=1, scale=1.0 / np.sqrt(cin)).numpy()
+    b = rnd(cout, seed=2, scale=0.1).numpy()
+    dual = mode != capi.MODE_LINEAR
+    co = cout // 2 if dual else cout
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        R = rag.total_rows
+        cw = packing.pack_conv(w, b, ops.device, mode=mode, bf16=True)
+        x = to(rnd(R, cin, seed=3))
+        y = to(rnd(R, co, seed=4))
+        res = to(rnd(R, co, seed=5))
+        pre = to(rnd(R, 2 * co if dual else co, seed=6))
+        sv = to(rnd(len(lengths), co, seed=7))
+        ops.conv(cw, x, y, rag, pre=capi.PRE_LRELU, pre_slope=0.1, act=capi.ACT_TANH, alpha=0.5, seqvec=sv, preadd=pre, res=res,
+                 res_scale=0.25, accumulate=True, compute=compute)
+        return y
+
+    gpu.small_tile_blocks = 1 << 30
+    try:
+        g, c = both(gpu, cpu, run)
+    finally:
+        gpu.small_tile_blocks = 1536
+    close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
