@@ -697,10 +697,11 @@ static bool gemm_rows_ok(const TtsConvDesc& d) {
   // Measured on MI355X (tools/microbench_small.py): fp32 gains 25-40 % at every size (K = 192: 15.5 -> 11.5 us, K = 1536:
   // 78 -> 48 us; its MFMAs are 8x longer per byte loaded).  bf16 gains at latency-bound grid sizes (K = 1536, 30 workgroups:
   // 39 -> 29 us; K = 192: 11.5 -> 9.5 us) and is neutral once the grid fills the chip, where the LDS-staged form shares each
-  // operand between two wavefronts - so bf16 takes this path for grids up to two workgroups per CU only.
+  // operand between two wavefronts (crossover measured at ~one workgroup per CU: K = 192 x N = 576 loses from 360
+  // workgroups on, K = 1536 x N = 192 from 384) - so bf16 takes this path for grids up to 256 workgroups only.
   if (d.compute != 0 && std::getenv("TOUCAN_GEMM_ROWS_BF16") == nullptr) {
     const int cols = d.mode != TTS_MODE_LINEAR ? d.half_pad : d.wn;
-    if ((long long)d.n_tiles * (cols / 64) > 512) return false;
+    if ((long long)d.n_tiles * (cols / 64) > 256) return false;
   }
   if ((d.ldx & (xb ? 7 : 3)) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0) return false;
   return std::getenv("TOUCAN_NO_GEMM_ROWS") == nullptr;  // escape hatch for A/B measurements

@@ -15,9 +15,12 @@ from ims_toucan_prosody_variance_amd.ragged import Ragged
 def main():
     dev = torch.device("cuda:0")
     ops = engine.Ops(dev)
-    shapes = [("WN gated k5", 320, 192, 384, 5, capi.MODE_GATED), ("FFN2 dec", 640, 1536, 192, 1, capi.MODE_LINEAR),
-              ("FFN1 dec", 640, 192, 1536, 1, capi.MODE_LINEAR), ("qkv dec", 640, 192, 576, 1, capi.MODE_LINEAR),
-              ("FFN2 enc", 128, 1536, 192, 1, capi.MODE_LINEAR), ("out enc", 128, 192, 192, 1, capi.MODE_LINEAR)]
+    if len(sys.argv) > 1:  # python tools/microbench_small.py M [M ...]: the 1-tap shapes at other row counts
+        shapes = [(f"K{cin} N{cout}", int(m), cin, cout, 1, capi.MODE_LINEAR) for m in sys.argv[1:] for cin, cout in ((192, 192), (192, 576), (1536, 192))]
+    else:
+        shapes = [("WN gated k5", 320, 192, 384, 5, capi.MODE_GATED), ("FFN2 dec", 640, 1536, 192, 1, capi.MODE_LINEAR),
+                  ("FFN1 dec", 640, 192, 1536, 1, capi.MODE_LINEAR), ("qkv dec", 640, 192, 576, 1, capi.MODE_LINEAR),
+                  ("FFN2 enc", 128, 1536, 192, 1, capi.MODE_LINEAR), ("out enc", 128, 192, 192, 1, capi.MODE_LINEAR)]
     for name, M, cin, cout, k, mode in shapes:
         rs = np.random.RandomState(0)
         cw = packing.pack_conv((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32), np.zeros(cout, np.float32), dev, mode=mode, bf16=True)
