@@ -330,21 +330,25 @@ def test_library_rejects_bad_arguments(gpu):
         gpu.conv(cw, gpu.empty(10, 32), gpu.empty(10, 32), rag)
 
 
-@pytest.mark.parametrize("cin,cout,mode,lengths", [
-    (64, 192, capi.MODE_LINEAR, [1, 1, 1, 1, 1]),       # one row per utterance (the conditional-layer-norm MLPs)
-    (192, 192, capi.MODE_LINEAR, [7]),
-    (1536, 192, capi.MODE_LINEAR, [130]),
-    (192, 576, capi.MODE_LINEAR, [97, 5]),
-    (256, 256, capi.MODE_LINEAR, [1, 1, 1]),
-    (192, 384, capi.MODE_GLU, [33, 128]),
-    (192, 1536, capi.MODE_LINEAR, [64, 65]),
+@pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", [
+    (64, 192, 1, 1, capi.MODE_LINEAR, [1, 1, 1, 1, 1]),       # one row per utterance (the conditional-layer-norm MLPs)
+    (192, 192, 1, 1, capi.MODE_LINEAR, [7]),
+    (1536, 192, 1, 1, capi.MODE_LINEAR, [130]),
+    (192, 576, 1, 1, capi.MODE_LINEAR, [97, 5]),
+    (256, 256, 1, 1, capi.MODE_LINEAR, [1, 1, 1]),
+    (192, 384, 1, 1, capi.MODE_GLU, [33, 128]),
+    (192, 1536, 1, 1, capi.MODE_LINEAR, [64, 65]),
+    (192, 384, 5, 1, capi.MODE_GATED, [63, 21, 1]),           # PostFlow WaveNet layer: taps shift the A rows, zero outside the utterance
+    (192, 256, 3, 1, capi.MODE_LINEAR, [64, 3, 129]),
+    (256, 256, 5, 2, capi.MODE_LINEAR, [7, 1, 40]),
 ])
 @pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
-def test_conv1d_one_tap_rows_kernel(gpu, cpu, cin, cout, mode, lengths, compute, monkeypatch):
-    """1-tap convs with 16-byte aligned contiguous rows take the LDS-free kernel in the small-batch form (fp32 by default, bf16 when
-    TOUCAN_GEMM_ROWS_BF16 is set); every epilogue feature, against the emulator."""
+def test_conv1d_rows_kernel(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, monkeypatch):
+    """1-tap convs with 16-byte aligned contiguous rows take the LDS-free kernel in the small-batch form (fp32 always, bf16 on
+    latency-bound grids or when TOUCAN_GEMM_ROWS_BF16 is set); the multi-tap cases run the LDS-staged small form on the same
+    aligned inputs (double-buffered window).  Every epilogue feature, against the emulator."""
     monkeypatch.setenv("TOUCAN_GEMM_ROWS_BF16", "1")
-    w = rnd(cout, cin, 1, seed=1, scale=1.0 / np.sqrt(cin)).numpy()
+    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
     b = rnd(cout, seed=2, scale=0.1).numpy()
     dual = mode != capi.MODE_LINEAR
     co = cout // 2 if dual else cout
@@ -352,7 +356,7 @@ def test_conv1d_one_tap_rows_kernel(gpu, cpu, cin, cout, mode, lengths, compute,
     def run(ops, to):
         rag = Ragged(lengths, ops.device, align=2)
         R = rag.total_rows
-        cw = packing.pack_conv(w, b, ops.device, mode=mode, bf16=True)
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode, bf16=True)
         x = to(rnd(R, cin, seed=3))
         y = to(rnd(R, co, seed=4))
         res = to(rnd(R, co, seed=5))
