@@ -113,7 +113,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   constexpr int UPT = (UNITS + RB_THREADS - 1) / RB_THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
-  const TtsTile tile = d.tiles[blockIdx.x];
+  // Workgroups are dealt to the 8 XCDs round-robin (b % 8); neighbouring tiles share their halo rows, so give every XCD a
+  // contiguous run of tiles: its private L2 then serves the halo the neighbour already fetched.
+  // (XCD x owns q + (x < r) consecutive tiles, q = n / 8, r = n % 8: a bijection for every n)
+  const int q8 = d.n_tiles >> 3, r8 = d.n_tiles & 7, xcd = blockIdx.x & 7;
+  const int tile_idx = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
+  const TtsTile tile = d.tiles[tile_idx];
+
   const int h1 = (d.taps - 1) / 2 * d.dil, h2 = (d.taps - 1) / 2;
   const int win_rows = RB_M1 + 2 * h1;
   // xa (act1(x) window) is dead once conv1 has finished, so t1 (conv1 output) overlays it
