@@ -342,23 +342,27 @@ class AcousticEngine:
             pa, pn, pcp = (f"post_flow.flows.{3 * b + i}." for i in range(3))
             blk = dict(an_bias=_dev(sd[pa + "bias"].reshape(-1), dev), an_logs=_dev(sd[pa + "logs"].reshape(-1), dev),
                        winv=_dev(packing.invconv_inverse(sd, pn), dev),
-                       start=pcb(sd[pcp + "start.weight"], sd[pcp + "start.bias"], dev),
+                       start=pcb(*self._start_with_zeroed_skip(sd[pcp + "start.weight"], sd[pcp + "start.bias"]), dev),
                        end=pc(sd[pcp + "end.weight"], sd[pcp + "end.bias"], dev, mode=MODE_COUPLING),  # m, logs: keep fp32
                        cond=pcb(sd[pcp + "wn.cond_layer.weight"], sd[pcp + "wn.cond_layer.bias"], dev))
             if b % 4 == 0 or not self.flow:  # in/res-skip layers are shared inside groups of 4 blocks (Glow.py:325-327)
-                shared = dict(inl=[], res=[], skip=[])
+                shared = dict(inl=[], res_skip=[])
                 for i in range(4):
                     shared["inl"].append(pcb(sd[pcp + f"wn.in_layers.{i}.weight"], sd[pcp + f"wn.in_layers.{i}.bias"], dev, mode=MODE_GATED))
-                    rw, rb = sd[pcp + f"wn.res_skip_layers.{i}.weight"], sd[pcp + f"wn.res_skip_layers.{i}.bias"]
-                    if i < 3:  # first half feeds the residual stream, second half the skip sum (wavenet.py:112-118)
-                        shared["res"].append(pcb(rw[:ATT], rb[:ATT], dev))
-                        shared["skip"].append(pcb(rw[ATT:], rb[ATT:], dev))
-                    else:
-                        shared["res"].append(None)
-                        shared["skip"].append(pcb(rw, rb, dev))
+                    # layers 0-2: 384 outputs, first half feeds the residual stream, second half the skip sum (wavenet.py:112-118);
+                    # the hidden state and the skip sum live side by side in one [rows, 384] tensor, so ONE accumulating conv
+                    # updates both.  Layer 3: 192 outputs, skip only.
+                    shared["res_skip"].append(pcb(sd[pcp + f"wn.res_skip_layers.{i}.weight"], sd[pcp + f"wn.res_skip_layers.{i}.bias"], dev))
             blk.update(shared)
             self.flow.append(blk)
         self._pe_cache = {}
+
+    @staticmethod
+    def _start_with_zeroed_skip(w, b):
+        """CouplingBlock.start (Glow.py:232-241) widened from 192 to 384 outputs with zero weights: the extra half lands in the
+        skip-sum columns that sit next to the hidden state, so the launch that starts a block also clears its skip sum."""
+        w, b = np.asarray(w, dtype=np.float32), np.asarray(b, dtype=np.float32)
+        return np.concatenate([w, np.zeros_like(w)], axis=0), np.concatenate([b, np.zeros_like(b)], axis=0)
 
     # ---- relative position tables -----------------------------------------------------------------
     def _ensure_ptabs(self, cw, pmax):
@@ -581,19 +585,17 @@ class AcousticEngine:
         g_sq = g.view(RS, 2 * ATT)  # squeeze == re-view in time-major layout (glow_utils.py:28-40)
         x = ops.empty(RS, 160)
         x.copy_(z_sq)
-        h = ops.empty(RS, ATT)
+        hs = ops.empty(RS, 2 * ATT)  # [hidden state | skip sum] side by side: one accumulating conv per WaveNet layer updates both
+        h, skip = hs[:, :ATT], hs[:, ATT:]
         acts = ops.empty(RS, ATT)
-        skip = ops.empty(RS, ATT)
         cond = ops.empty(RS, 8 * ATT)
         for b in reversed(range(18)):
             blk = self.flow[b]
-            ops.conv(blk["start"], x[:, :80], h, rag_s)
+            ops.conv(blk["start"], x[:, :80], hs, rag_s)  # h = start(x0); the zero-weight second half clears the skip sum
             ops.conv(blk["cond"], g_sq, cond, rag_s)
             for i in range(4):
                 ops.conv(blk["inl"][i], h, acts, rag_s, preadd=cond[:, i * 2 * ATT:(i + 1) * 2 * ATT])
-                if i < 3:
-                    ops.conv(blk["res"][i], acts, h, rag_s, res=h)
-                ops.conv(blk["skip"][i], acts, skip, rag_s, accumulate=(i > 0))
+                ops.conv(blk["res_skip"][i], acts, hs if i < 3 else skip, rag_s, accumulate=True)  # h += res, skip += skip_out
             x1 = x[:, 80:]
             ops.conv(blk["end"], skip, x1, rag_s, aux=x1)
             ops.glow_invconv_actnorm(x, RS, 160, blk["winv"], blk["an_bias"], blk["an_logs"])
