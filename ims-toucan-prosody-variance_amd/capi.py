@@ -73,6 +73,8 @@ PROTOTYPES = {
     "tts_resblock_tile_rows": (C.c_int, [_i]),
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
+    "tts_cln_mlp_weight_floats": (C.c_int64, [_i, _i]),
+    "tts_cln_mlp": (C.c_int, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "tts_l2_normalize": (C.c_int, [_p, _p, _i, _i, _p]),
     "tts_groupnorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _i, _i, _p, _p]),
     "tts_groupnorm_workspace_floats": (C.c_int64, [_i, _i, _i]),
@@ -89,7 +91,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 4  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 5  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

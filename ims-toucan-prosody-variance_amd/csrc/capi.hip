@@ -23,6 +23,8 @@ int conv1d_n_tile(int cout, int mode);
 int conv1d_small_tile_rows(int cout, int mode, int packed_cols);
 int layernorm(const float*, int, float*, int, const float*, const float*, int, int, float, hipStream_t);
 int cond_layernorm(const float*, int, float*, int, const float*, const float*, int, const TtsTile*, int, int, hipStream_t);
+long long cln_mlp_weight_floats(int, int);
+int cln_mlp(const float*, int, int, int, const float*, int, float*, hipStream_t);
 int l2_normalize(const float*, float*, int, int, hipStream_t);
 int groupnorm(const float*, int, float*, int, const float*, const float*, int, int, float, int, const float*, int, const int*,
               const int*, int, int, float*, hipStream_t);
@@ -80,6 +82,11 @@ int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const floa
   return tts::layernorm(x, ldx, y, ldy, gamma, beta, rows, c, eps, ST(stream));
 }
 
+int64_t tts_cln_mlp_weight_floats(int32_t d_in, int32_t d_out) { return tts::cln_mlp_weight_floats(d_in, d_out); }
+int tts_cln_mlp(const float* e, int32_t n_seq, int32_t d_in, int32_t d_out, const float* weights, int32_t n_mlp, float* out,
+                tts_stream_t stream) {
+  return tts::cln_mlp(e, n_seq, d_in, d_out, weights, n_mlp, out, ST(stream));
+}
 int tts_cond_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* scale, const float* shift, int32_t c,
                        const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream) {
   return tts::cond_layernorm(x, ldx, y, ldy, scale, shift, c, tiles, n_tiles, tile_rows, ST(stream));

@@ -141,6 +141,12 @@ class Ops:
                                                tiles.data_ptr(), n, 64, self.stream()), "tts_cond_layernorm")
         return y
 
+    def cln_mlp(self, e_norm, weights, n_mlp, d_in, d_out):
+        out = self.empty(n_mlp, e_norm.shape[0], d_out)
+        capi.check(self.lib.tts_cln_mlp(e_norm.data_ptr(), e_norm.shape[0], d_in, d_out, weights.data_ptr(), n_mlp, out.data_ptr(),
+                                        self.stream()), "tts_cln_mlp")
+        return out
+
     def l2_normalize(self, x, y):
         capi.check(self.lib.tts_l2_normalize(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], self.stream()), "tts_l2_normalize")
         return y
@@ -317,17 +323,24 @@ class AcousticEngine:
         self.hs_h = pcb(hs[:, :ATT], None, dev)  # acts on the hidden states
         self.hs_e = pc(hs[:, ATT:], sd["encoder.hs_emb_projection.bias"], dev)  # acts on the utterance embedding (+ bias)
         self.pred = {}
+        cln_blocks = []
         for name, layers, k in (("pitch_predictor", 7, 5), ("energy_predictor", 2, 3), ("duration_predictor", 3, 3)):
             convs = [pc(sd[f"{name}.conv.{i}.0.weight"], sd[f"{name}.conv.{i}.0.bias"], dev) for i in range(layers)]
-            mlps = []
+            first = len(cln_blocks) // 2  # index of this predictor's first conditional layer norm
             for i in range(layers):
-                m = {}
-                for which in ("W_scale", "W_bias"):
+                for which in ("W_scale", "W_bias"):  # ConditionalLayerNorm.py:26-35: Linear, Tanh, Linear, Tanh, Linear
                     q = f"{name}.norms.{i}.{which}."
-                    m[which] = [pc(sd[q + f"{j}.weight"], sd[q + f"{j}.bias"], dev) for j in (0, 2, 4)]
-                mlps.append(m)
+                    parts = []
+                    for j in (0, 2, 4):
+                        parts += [np.ascontiguousarray(np.asarray(sd[q + f"{j}.weight"], dtype=np.float32).T).reshape(-1),
+                                  np.asarray(sd[q + f"{j}.bias"], dtype=np.float32).reshape(-1)]
+                    cln_blocks.append(np.concatenate(parts))
             lin = pc(sd[name + ".linear.weight"], sd[name + ".linear.bias"], dev)
-            self.pred[name] = (convs, mlps, lin)
+            self.pred[name] = (convs, first, lin)
+        # every scale / shift MLP of the 12 conditional layer norms in one buffer -> one tts_cln_mlp launch per forward
+        self.cln_weights = _dev(np.concatenate(cln_blocks), dev)
+        self.n_cln_mlp = len(cln_blocks)
+        assert cln_blocks[0].size == self.ops.lib.tts_cln_mlp_weight_floats(64, 256)
         self.pitch_w = _dev(sd["pitch_embed.0.weight"].reshape(-1), dev)
         self.pitch_b = _dev(sd["pitch_embed.0.bias"], dev)
         self.energy_w = _dev(sd["energy_embed.0.weight"].reshape(-1), dev)
@@ -409,23 +422,17 @@ class AcousticEngine:
                 taps[f"{tap_name}_block{li}"] = x.clone()
         return x
 
-    def _predictor(self, name, enc, e_norm, rag, rag_b):
-        """Layers/VariancePredictor.py:65-80 / DurationPredictor.py:63-74 with ConditionalLayerNorm.py:52-67."""
+    def _predictor(self, name, enc, cln, rag):
+        """Layers/VariancePredictor.py:65-80 / DurationPredictor.py:63-74 with ConditionalLayerNorm.py:52-67.
+        cln: [n_mlp, B, 256] scale / shift vectors of every conditional layer norm (tts_cln_mlp)."""
         ops = self.ops
-        convs, mlps, lin = self.pred[name]
-        R, B = enc.shape[0], e_norm.shape[0]
+        convs, first, lin = self.pred[name]
+        R = enc.shape[0]
         h = enc
         a, bbuf = ops.empty(R, 256), ops.empty(R, 256)
-        t64, t256 = ops.empty(B, 64), ops.empty(B, 256)
         for i, cw in enumerate(convs):
-            sc_sh = []
-            for which in ("W_scale", "W_bias"):
-                m = mlps[i][which]
-                ops.conv(m[0], e_norm, t64, rag_b, act=ACT_TANH)
-                ops.conv(m[1], t64, t256, rag_b, act=ACT_TANH)
-                sc_sh.append(ops.conv(m[2], t256, ops.empty(B, 256), rag_b))
             ops.conv(cw, h, a, rag, act=ACT_RELU)
-            ops.cond_layernorm(a, bbuf, sc_sh[0], sc_sh[1], 256, rag)
+            ops.cond_layernorm(a, bbuf, cln[2 * (first + i)], cln[2 * (first + i) + 1], 256, rag)
             h = bbuf  # the next conv reads bbuf into a, then the norm overwrites bbuf: no aliasing
         out = ops.empty(R, 1)
         ops.conv(lin, h, out, rag)
@@ -448,19 +455,22 @@ class AcousticEngine:
         ops.layernorm(x, x, *self.out_norm, R, ATT)
         e_proj = ops.conv(self.hs_e, e_norm, ops.empty(B, ATT), rag_b)
         enc = ops.conv(self.hs_h, x, ops.empty(R, ATT), rag_p, seqvec=e_proj)
+        cln = None
+        if gold_p is None or gold_e is None or gold_d is None:
+            cln = ops.cln_mlp(e_norm, self.cln_weights, self.n_cln_mlp, 64, 256)  # [n_mlp, B, 256]: all scale / shift vectors at once
         if gold_p is None:
-            p = self._predictor("pitch_predictor", enc, e_norm, rag_p, rag_b)
+            p = self._predictor("pitch_predictor", enc, cln, rag_p)
         else:
             p = ops.empty(R)
             p.copy_(gold_p)
         if gold_e is None:
-            en = self._predictor("energy_predictor", enc, e_norm, rag_p, rag_b)
+            en = self._predictor("energy_predictor", enc, cln, rag_p)
         else:
             en = ops.empty(R)
             en.copy_(gold_e)
         d = ops.empty(R, dtype=torch.int32)
         if gold_d is None:
-            logd = self._predictor("duration_predictor", enc, e_norm, rag_p, rag_b)
+            logd = self._predictor("duration_predictor", enc, cln, rag_p)
             ops.duration_from_log(logd, d)
             if taps is not None:
                 taps["log_dur"] = logd.clone()

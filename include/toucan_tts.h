@@ -133,6 +133,16 @@ int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const floa
 int tts_cond_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* scale, const float* shift,
                        int32_t c, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
 
+/* The scale / shift MLPs of every ConditionalLayerNorm in one launch (Layers/ConditionalLayerNorm.py:26-35, 54-55:
+ * Linear(d_in,d_in) Tanh Linear(d_in,d_out) Tanh Linear(d_out,d_out) applied to the normalised utterance embedding).
+ * e: [n_seq, d_in]; out: [n_mlp, n_seq, d_out] (MLP m's rows are contiguous, ready to be tts_cond_layernorm's scale / shift);
+ * weights: n_mlp blocks of tts_cln_mlp_weight_floats(d_in, d_out) floats, each
+ *   [W0^T (d_in x d_in) | b0 (d_in) | W1^T (d_in x d_out) | b1 (d_out) | W2^T (d_out x d_out) | b2 (d_out)], W^T = [in][out].
+ * d_in <= d_out <= 256. */
+int64_t tts_cln_mlp_weight_floats(int32_t d_in, int32_t d_out);
+int tts_cln_mlp(const float* e, int32_t n_seq, int32_t d_in, int32_t d_out, const float* weights, int32_t n_mlp, float* out,
+                tts_stream_t stream);
+
 /* Row-wise L2 normalisation (torch.nn.functional.normalize, eps 1e-12). InferenceToucanTTS.py:202, Conformer.py:132. */
 int tts_l2_normalize(const float* x, float* y, int32_t rows, int32_t c, tts_stream_t stream);
 
@@ -206,7 +216,7 @@ int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float*
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 4
+#define TTS_ABI_VERSION 5
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -242,6 +242,26 @@ class Emulator:
             _mat(y, se, c, ldy)[sb:se] = (sc * ((X - m) / v) + sh).astype(np.float32)
         return 0
 
+    def tts_cln_mlp_weight_floats(self, d_in, d_out):
+        return d_in * d_in + d_in + d_in * d_out + d_out + d_out * d_out + d_out
+
+    def tts_cln_mlp(self, e, n_seq, d_in, d_out, weights, n_mlp, out, stream):
+        self._count("cln_mlp")
+        per = self.tts_cln_mlp_weight_floats(d_in, d_out)
+        E = _mat(e, n_seq, d_in, d_in).astype(np.float64)
+        W = _arr(weights, n_mlp * per).astype(np.float64).reshape(n_mlp, per)
+        O = _arr(out, n_mlp * n_seq * d_out).reshape(n_mlp, n_seq, d_out)
+        for m in range(n_mlp):
+            o = 0
+            w0 = W[m, o:o + d_in * d_in].reshape(d_in, d_in); o += d_in * d_in
+            b0 = W[m, o:o + d_in]; o += d_in
+            w1 = W[m, o:o + d_in * d_out].reshape(d_in, d_out); o += d_in * d_out
+            b1 = W[m, o:o + d_out]; o += d_out
+            w2 = W[m, o:o + d_out * d_out].reshape(d_out, d_out); o += d_out * d_out
+            b2 = W[m, o:o + d_out]
+            O[m] = (np.tanh(np.tanh(E @ w0 + b0) @ w1 + b1) @ w2 + b2).astype(np.float32)
+        return 0
+
     def tts_l2_normalize(self, x, y, rows, c, stream):
         self._count("l2_normalize")
         X = _mat(x, rows, c, c).astype(np.float64)

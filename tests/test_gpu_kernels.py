@@ -372,3 +372,19 @@ def test_conv1d_rows_kernel(gpu, cpu, cin, cout, k, dil, mode, lengths, compute,
     finally:
         gpu.small_tile_blocks = 1536
     close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
+
+
+@pytest.mark.parametrize("n_seq,n_mlp,d_in,d_out", [(1, 24, 64, 256), (5, 3, 64, 256), (32, 24, 64, 256), (2, 2, 32, 48)])
+def test_cln_mlp(gpu, cpu, n_seq, n_mlp, d_in, d_out):
+    """All conditional-layer-norm scale / shift MLPs in one launch vs the fp64 emulator."""
+    per = d_in * d_in + d_in + d_in * d_out + d_out + d_out * d_out + d_out
+    assert capi.lib().tts_cln_mlp_weight_floats(d_in, d_out) == per
+    w = rnd(n_mlp, per, seed=1, scale=0.2)
+    e = torch.nn.functional.normalize(rnd(n_seq, d_in, seed=2), dim=1)
+
+    def run(ops, to):
+        return ops.cln_mlp(to(e), to(w).reshape(-1), n_mlp, d_in, d_out)
+
+    g, c = both(gpu, cpu, run)
+    assert tuple(g.shape) == (n_mlp, n_seq, d_out)
+    close(g, c, 2e-6)
