@@ -62,7 +62,7 @@ class Ops:
         if compute is None:
             compute = self.default_compute
         tile_rows = cw.tile_rows
-        if self.small_tile_blocks and cw.small_tile_rows:
+        if self.small_tile_blocks and cw.small_tile_rows and not cw.small_only:
             # grid of the regular form; when it cannot fill the chip, the 64 x 64 form runs ~3x more workgroups
             cols = cw.wn if cw.mode == MODE_LINEAR else cw.half_pad
             if -(-rag.total_rows // cw.tile_rows) * (cols // cw.n_tile) < self.small_tile_blocks:
@@ -356,7 +356,7 @@ class AcousticEngine:
             blk = dict(an_bias=_dev(sd[pa + "bias"].reshape(-1), dev), an_logs=_dev(sd[pa + "logs"].reshape(-1), dev),
                        winv=_dev(packing.invconv_inverse(sd, pn), dev),
                        start=pcb(*self._start_with_zeroed_skip(sd[pcp + "start.weight"], sd[pcp + "start.bias"]), dev),
-                       end=pc(sd[pcp + "end.weight"], sd[pcp + "end.bias"], dev, mode=MODE_COUPLING),  # m, logs: keep fp32
+                       end=pc(sd[pcp + "end.weight"], sd[pcp + "end.bias"], dev, mode=MODE_COUPLING, small_only=True),  # m, logs: keep fp32
                        cond=pcb(sd[pcp + "wn.cond_layer.weight"], sd[pcp + "wn.cond_layer.bias"], dev))
             if b % 4 == 0 or not self.flow:  # in/res-skip layers are shared inside groups of 4 blocks (Glow.py:325-327)
                 shared = dict(inl=[], res_skip=[])

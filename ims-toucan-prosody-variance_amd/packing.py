@@ -53,7 +53,7 @@ def _roundup(a, b):
 class ConvWeights:
     """One packed conv: device tensors + the static fields of TtsConvDesc."""
 
-    def __init__(self, w_kio, bias, mode, dil, pad_left, device, bf16=False):
+    def __init__(self, w_kio, bias, mode, dil, pad_left, device, bf16=False, small_only=False):
         # w_kio: numpy [taps, cin, cout_total] (dual modes: cout_total = 2*cout, halves [a | g])
         lib = capi.lib()
         taps, cin, ctot = w_kio.shape
@@ -66,10 +66,18 @@ class ConvWeights:
         self.cout = ctot // 2 if dual else ctot
         self.n_tile = lib.tts_conv1d_n_tile(self.cout, mode)
         self.tile_rows = lib.tts_conv1d_tile_rows(self.cout, mode)
+        # small_only: pad the columns to the 64-column small-batch form instead of the regular N tile and always run that form
+        # (narrow dual-mode convs such as the 80-channel coupling output would otherwise get one 128 x 96 workgroup per 128 rows)
+        self.small_only = bool(small_only)
+        if self.small_only:
+            self.n_tile = 64
         half = _roundup(self.cout, self.n_tile)
         self.half_pad = half if dual else 0
         self.wn = 2 * half if dual else half
         self.small_tile_rows = lib.tts_conv1d_small_tile_rows(self.cout, mode, half)  # 64 or 0 (small-batch form)
+        if self.small_only:
+            assert self.small_tile_rows == 64, "this shape has no small-batch form"
+            self.tile_rows = 64
         packed = np.zeros((taps, self.cin_pad, self.wn), dtype=np.float32)
         if dual:
             packed[:, :cin, : self.cout] = w_kio[:, :, : self.cout]
@@ -85,14 +93,14 @@ class ConvWeights:
         self.bias = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, dtype=np.float32)).to(device)
 
 
-def pack_conv(weight, bias, device, dil=1, mode=capi.MODE_LINEAR, bf16=False):
+def pack_conv(weight, bias, device, dil=1, mode=capi.MODE_LINEAR, bf16=False, small_only=False):
     """torch Conv1d weight [cout, cin, k] ('same' padding (k-1)/2*dil) or Linear weight [cout, cin]."""
     w = _np(weight)
     if w.ndim == 2:
         w = w[:, :, None]
     k = w.shape[2]
     w_kio = np.ascontiguousarray(np.transpose(w, (2, 1, 0)))
-    return ConvWeights(w_kio, None if bias is None else _np(bias), mode, dil, (k - 1) // 2 * dil, device, bf16)
+    return ConvWeights(w_kio, None if bias is None else _np(bias), mode, dil, (k - 1) // 2 * dil, device, bf16, small_only)
 
 
 def pack_conv_transpose(weight, bias, stride, device, bf16=False):
