@@ -396,7 +396,9 @@ class AcousticEngine:
         R = x.shape[0]
         self._ensure_ptabs(cw, rag.max_len)
         ln = ops.empty(R, ATT)
-        hid = ops.empty(R, 1536)
+        # tensors consumed only by bf16-MFMA convs are kept as bf16 in HBM: the consumer would round them to bf16 while staging
+        # anyway (same round-to-nearest-even), so the result is bit-identical and the round trip costs half the bytes
+        hid = ops.empty(R, 1536, dtype=torch.bfloat16 if self.bf16 else torch.float32)
         qkv = ops.empty(R, 3 * ATT)
         ctx = ops.empty(R, ATT)
         glu = ops.empty(R, ATT)
@@ -597,7 +599,7 @@ class AcousticEngine:
         x.copy_(z_sq)
         hs = ops.empty(RS, 2 * ATT)  # [hidden state | skip sum] side by side: one accumulating conv per WaveNet layer updates both
         h, skip = hs[:, :ATT], hs[:, ATT:]
-        acts = ops.empty(RS, ATT)
+        acts = ops.empty(RS, ATT, dtype=torch.bfloat16 if self.bf16 else torch.float32)  # read only by the res/skip conv (bf16 MFMA)
         cond = ops.empty(RS, 8 * ATT)
         for b in reversed(range(18)):
             blk = self.flow[b]
