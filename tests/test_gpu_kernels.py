@@ -388,3 +388,28 @@ def test_cln_mlp(gpu, cpu, n_seq, n_mlp, d_in, d_out):
     g, c = both(gpu, cpu, run)
     assert tuple(g.shape) == (n_mlp, n_seq, d_out)
     close(g, c, 2e-6)
+
+
+@pytest.mark.parametrize("cin,cout,mode,lengths", [(1536, 192, capi.MODE_LINEAR, [130, 7]), (192, 384, capi.MODE_GLU, [33]), (256, 256, capi.MODE_LINEAR, [1, 1])])
+@pytest.mark.parametrize("pre", [capi.PRE_NONE, capi.PRE_LRELU])
+def test_conv1d_rows_kernel_bf16_input(gpu, cpu, cin, cout, mode, lengths, pre, monkeypatch):
+    """The LDS-free 1-tap kernel reading a bf16 tensor (the FFN hidden state / WaveNet gate activations of the bf16 configuration)."""
+    monkeypatch.setenv("TOUCAN_GEMM_ROWS_BF16", "1")
+    w = rnd(cout, cin, 1, seed=1, scale=1.0 / np.sqrt(cin)).numpy()
+    b = rnd(cout, seed=2, scale=0.1).numpy()
+    co = cout // 2 if mode != capi.MODE_LINEAR else cout
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        cw = packing.pack_conv(w, b, ops.device, mode=mode, bf16=True)
+        x = to(rnd(rag.total_rows, cin, seed=3)).to(torch.bfloat16)
+        y = to(rnd(rag.total_rows, co, seed=4))
+        ops.conv(cw, x, y, rag, pre=pre, pre_slope=0.1, res=to(rnd(rag.total_rows, co, seed=5)), compute=capi.COMPUTE_BF16)
+        return y
+
+    gpu.small_tile_blocks = 1 << 30
+    try:
+        g, c = both(gpu, cpu, run)
+    finally:
+        gpu.small_tile_blocks = 1536
+    close(g, c, 2e-2)
