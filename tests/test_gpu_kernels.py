@@ -62,6 +62,8 @@ CONV_CASES = [
     (272, 192, 5, 1, capi.MODE_LINEAR, [88]),
     (192, 256, 7, 3, capi.MODE_LINEAR, [100, 37]),   # small form: halo 18 (bf16 window falls back to synchronous staging, fp32 prefetches)
     (96, 128, 11, 5, capi.MODE_LINEAR, [90]),        # small form: halo 50 (both fall back)
+    (192, 1536, 1, 1, capi.MODE_LINEAR, [700, 700, 100]),   # small form, grid >= 512 workgroups: 64 x 128 tiles
+    (192, 384, 3, 2, capi.MODE_LINEAR, [3000, 2600, 70]),   # 〃 with taps
     (192, 384, 1, 1, capi.MODE_GLU, [128, 33]),
     (192, 384, 5, 1, capi.MODE_GATED, [63, 21]),
     (192, 160, 1, 1, capi.MODE_COUPLING, [44, 63]),
