@@ -308,9 +308,7 @@ class AcousticEngine:
         dev = self.device
         sd = packing.fold_weight_norm(state_dict)
         self.multilingual = "encoder.language_embedding.weight" in sd
-        self.multispeaker = "encoder.hs_emb_projection.weight" in sd
-        if not self.multispeaker:
-            raise NotImplementedError("single-speaker checkpoints (LayerNorm predictors) are not supported by the HIP path yet")
+        self.multispeaker = "encoder.hs_emb_projection.weight" in sd  # else: utt_embed_dim=None variant (ToucanTTSInterface.py:61-63)
         pc = packing.pack_conv  # fp32 only (embedding, predictors, per-utterance vectors)
         pcb = lambda *a, **k: packing.pack_conv(*a, bf16=bf16, **k)
         self.embed0 = pc(sd["encoder.embed.0.weight"], sd["encoder.embed.0.bias"], dev)
@@ -319,14 +317,19 @@ class AcousticEngine:
         self.enc = ConformerWeights(sd, "encoder", 7, dev, bf16)
         self.dec = ConformerWeights(sd, "decoder", 31, dev, bf16)
         self.out_norm = (_dev(sd["encoder.output_norm.weight"], dev), _dev(sd["encoder.output_norm.bias"], dev))
-        hs = sd["encoder.hs_emb_projection.weight"]
-        self.hs_h = pcb(hs[:, :ATT], None, dev)  # acts on the hidden states
-        self.hs_e = pc(hs[:, ATT:], sd["encoder.hs_emb_projection.bias"], dev)  # acts on the utterance embedding (+ bias)
+        if self.multispeaker:
+            hs = sd["encoder.hs_emb_projection.weight"]
+            self.hs_h = pcb(hs[:, :ATT], None, dev)  # acts on the hidden states
+            self.hs_e = pc(hs[:, ATT:], sd["encoder.hs_emb_projection.bias"], dev)  # acts on the utterance embedding (+ bias)
         self.pred = {}
         cln_blocks = []
         for name, layers, k in (("pitch_predictor", 7, 5), ("energy_predictor", 2, 3), ("duration_predictor", 3, 3)):
             convs = [pc(sd[f"{name}.conv.{i}.0.weight"], sd[f"{name}.conv.{i}.0.bias"], dev) for i in range(layers)]
             first = len(cln_blocks) // 2  # index of this predictor's first conditional layer norm
+            if not self.multispeaker:  # plain LayerNorm(256) per layer (VariancePredictor.py:47-48 / DurationPredictor.py:57-58)
+                norms = [(_dev(sd[f"{name}.norms.{i}.weight"], dev), _dev(sd[f"{name}.norms.{i}.bias"], dev)) for i in range(layers)]
+                self.pred[name] = (convs, norms, pc(sd[name + ".linear.weight"], sd[name + ".linear.bias"], dev))
+                continue
             for i in range(layers):
                 for which in ("W_scale", "W_bias"):  # ConditionalLayerNorm.py:26-35: Linear, Tanh, Linear, Tanh, Linear
                     q = f"{name}.norms.{i}.{which}."
@@ -338,9 +341,10 @@ class AcousticEngine:
             lin = pc(sd[name + ".linear.weight"], sd[name + ".linear.bias"], dev)
             self.pred[name] = (convs, first, lin)
         # every scale / shift MLP of the 12 conditional layer norms in one buffer -> one tts_cln_mlp launch per forward
-        self.cln_weights = _dev(np.concatenate(cln_blocks), dev)
         self.n_cln_mlp = len(cln_blocks)
-        assert cln_blocks[0].size == self.ops.lib.tts_cln_mlp_weight_floats(64, 256)
+        if cln_blocks:
+            self.cln_weights = _dev(np.concatenate(cln_blocks), dev)
+            assert cln_blocks[0].size == self.ops.lib.tts_cln_mlp_weight_floats(64, 256)
         self.pitch_w = _dev(sd["pitch_embed.0.weight"].reshape(-1), dev)
         self.pitch_b = _dev(sd["pitch_embed.0.bias"], dev)
         self.energy_w = _dev(sd["energy_embed.0.weight"].reshape(-1), dev)
@@ -434,7 +438,10 @@ class AcousticEngine:
         a, bbuf = ops.empty(R, 256), ops.empty(R, 256)
         for i, cw in enumerate(convs):
             ops.conv(cw, h, a, rag, act=ACT_RELU)
-            ops.cond_layernorm(a, bbuf, cln[2 * (first + i)], cln[2 * (first + i) + 1], 256, rag)
+            if self.multispeaker:
+                ops.cond_layernorm(a, bbuf, cln[2 * (first + i)], cln[2 * (first + i) + 1], 256, rag)
+            else:
+                ops.layernorm(a, bbuf, *first[i], R, 256)  # `first` is the list of (weight, bias) pairs in this variant
             h = bbuf  # the next conv reads bbuf into a, then the norm overwrites bbuf: no aliasing
         out = ops.empty(R, 1)
         ops.conv(lin, h, out, rag)
@@ -455,10 +462,13 @@ class AcousticEngine:
             taps["enc_embed_scaled"] = x.clone()
         x = self._conformer(self.enc, x, rag_p, taps, "enc")
         ops.layernorm(x, x, *self.out_norm, R, ATT)
-        e_proj = ops.conv(self.hs_e, e_norm, ops.empty(B, ATT), rag_b)
-        enc = ops.conv(self.hs_h, x, ops.empty(R, ATT), rag_p, seqvec=e_proj)
+        if self.multispeaker:  # Conformer.py:130-134: projection of [hidden | normalised utterance embedding]
+            e_proj = ops.conv(self.hs_e, e_norm, ops.empty(B, ATT), rag_b)
+            enc = ops.conv(self.hs_h, x, ops.empty(R, ATT), rag_p, seqvec=e_proj)
+        else:
+            enc = x
         cln = None
-        if gold_p is None or gold_e is None or gold_d is None:
+        if self.multispeaker and (gold_p is None or gold_e is None or gold_d is None):
             cln = ops.cln_mlp(e_norm, self.cln_weights, self.n_cln_mlp, 64, 256)  # [n_mlp, B, 256]: all scale / shift vectors at once
         if gold_p is None:
             p = self._predictor("pitch_predictor", enc, cln, rag_p)

@@ -123,12 +123,16 @@ def _conformer(sd, prefix, seed, kernel, n_blocks=6):
             sd[p + ln + ".bias"] = normal(p + ln + "b", (ATT,), seed, 0.1)
 
 
-def _predictor(sd, prefix, seed, n_layers, kernel, chans=256):
+def _predictor(sd, prefix, seed, n_layers, kernel, chans=256, multispeaker=True):
     for i in range(n_layers):
         cin = ATT if i == 0 else chans
         sd[f"{prefix}.conv.{i}.0.weight"] = _xavier(f"{prefix}.c{i}", (chans, cin, kernel), seed, gain=1.4)
         sd[f"{prefix}.conv.{i}.0.bias"] = normal(f"{prefix}.c{i}b", (chans,), seed, 0.05)
     for i in range(n_layers):
+        if not multispeaker:  # single-speaker variant: plain LayerNorm(n_chans, dim=1) (VariancePredictor.py:47-48)
+            sd[f"{prefix}.norms.{i}.weight"] = normal(f"{prefix}.n{i}w", (chans,), seed, 0.1, 1.0)
+            sd[f"{prefix}.norms.{i}.bias"] = normal(f"{prefix}.n{i}b", (chans,), seed, 0.1)
+            continue
         for which, b_last in (("W_scale", 1.0), ("W_bias", 0.0)):
             q = f"{prefix}.norms.{i}.{which}."
             # ConditionalLayerNorm.py:38-50 resets these to constants; small random weights keep the
@@ -193,8 +197,10 @@ def _glow(sd, seed):
         _weight_norm_pair(sd, fc + "wn.cond_layer", fc + "cond", (2 * ATT * GLOW_LAYERS, 2 * ATT, 1), seed)
 
 
-def acoustic_state_dict(seed: int = 1234, n_lang: int = N_LANG) -> dict:
-    """name -> numpy array, schema of InferenceToucanTTS.ToucanTTS (multilingual, multispeaker)."""
+def acoustic_state_dict(seed: int = 1234, n_lang: int = N_LANG, multispeaker: bool = True) -> dict:
+    """name -> numpy array, schema of InferenceToucanTTS.ToucanTTS: multilingual + multispeaker by default; n_lang=None gives the
+    single-language variant (lang_embs=None), multispeaker=False the single-speaker one (utt_embed_dim=None) - the three
+    variants ToucanTTSInterface.py:55-63 tries in turn."""
     sd = {}
     e = "encoder."
     sd[e + "embed.0.weight"] = _xavier(e + "e0", (100, 62), seed)
@@ -203,16 +209,18 @@ def acoustic_state_dict(seed: int = 1234, n_lang: int = N_LANG) -> dict:
     sd[e + "embed.2.bias"] = normal(e + "e2b", (ATT,), seed, 0.02)
     sd[e + "output_norm.weight"] = normal(e + "onw", (ATT,), seed, 0.1, 1.0)
     sd[e + "output_norm.bias"] = normal(e + "onb", (ATT,), seed, 0.1)
-    sd[e + "hs_emb_projection.weight"] = _xavier(e + "hs", (ATT, ATT + UTT), seed)
-    sd[e + "hs_emb_projection.bias"] = normal(e + "hsb", (ATT,), seed, 0.02)
-    sd[e + "language_embedding.weight"] = normal(e + "lang", (n_lang, ATT), seed, 0.1)
+    if multispeaker:
+        sd[e + "hs_emb_projection.weight"] = _xavier(e + "hs", (ATT, ATT + UTT), seed)
+        sd[e + "hs_emb_projection.bias"] = normal(e + "hsb", (ATT,), seed, 0.02)
+    if n_lang is not None:
+        sd[e + "language_embedding.weight"] = normal(e + "lang", (n_lang, ATT), seed, 0.1)
     _conformer(sd, "encoder", seed, kernel=7)
-    _predictor(sd, "duration_predictor", seed, 3, 3)
+    _predictor(sd, "duration_predictor", seed, 3, 3, multispeaker=multispeaker)
     # log-domain duration head (DurationPredictor.py:79): exp(x)-1 ~ 5 frames
     sd["duration_predictor.linear.weight"] = normal("durlin", (1, 256), seed, 0.03)
     sd["duration_predictor.linear.bias"] = np.array([np.log(6.0)], dtype=np.float32)
-    _predictor(sd, "pitch_predictor", seed, 7, 5)
-    _predictor(sd, "energy_predictor", seed, 2, 3)
+    _predictor(sd, "pitch_predictor", seed, 7, 5, multispeaker=multispeaker)
+    _predictor(sd, "energy_predictor", seed, 2, 3, multispeaker=multispeaker)
     sd["pitch_embed.0.weight"] = normal("pemb", (ATT, 1, 1), seed, 0.3)
     sd["pitch_embed.0.bias"] = normal("pembb", (ATT,), seed, 0.02)
     sd["energy_embed.0.weight"] = normal("eemb", (ATT, 1, 1), seed, 0.3)

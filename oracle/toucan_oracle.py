@@ -149,6 +149,8 @@ def encoder(text, utt_emb, lang_id, sd, taps=None):
         taps["enc_embed"] = x
     x = conformer_stack(x, sd, "encoder", 7, taps, "enc")
     x = layer_norm(x, sd["encoder.output_norm.weight"], sd["encoder.output_norm.bias"])
+    if "encoder.hs_emb_projection.weight" not in sd:  # single-speaker variant (utt_embed=None): Conformer.py:125-126 is skipped
+        return x
     e = F.normalize(utt_emb.unsqueeze(0))[0]  # Conformer.py:132 (idempotent with InferenceToucanTTS.py:202)
     x = F.linear(torch.cat([x, e.unsqueeze(0).expand(x.shape[0], -1)], dim=-1),
                  sd["encoder.hs_emb_projection.weight"], sd["encoder.hs_emb_projection.bias"])
@@ -176,7 +178,10 @@ def predictor(x, e, sd, prefix, n_layers, kernel):
     h = x
     for i in range(n_layers):
         y = F.conv1d(h.t().unsqueeze(0), sd[f"{prefix}.conv.{i}.0.weight"], sd[f"{prefix}.conv.{i}.0.bias"], padding=(kernel - 1) // 2)
-        h = conditional_layer_norm(torch.relu(y)[0].t(), e, sd, f"{prefix}.norms.{i}.")
+        if f"{prefix}.norms.{i}.weight" in sd:  # single-speaker variant: LayerNorm(n_chans, dim=1) (VariancePredictor.py:47-48)
+            h = layer_norm(torch.relu(y)[0].t(), sd[f"{prefix}.norms.{i}.weight"], sd[f"{prefix}.norms.{i}.bias"])
+        else:
+            h = conditional_layer_norm(torch.relu(y)[0].t(), e, sd, f"{prefix}.norms.{i}.")
     return F.linear(h, sd[prefix + ".linear.weight"], sd[prefix + ".linear.bias"])[:, 0]
 
 
@@ -299,7 +304,9 @@ class AcousticOracle:
                  duration_scaling_factor=1.0, pitch_variance_scale=1.0, energy_variance_scale=1.0,
                  pause_duration_scaling_factor=1.0, taps=None, run_postflow=True):
         sd = self.sd
-        e = F.normalize(utt_emb.unsqueeze(0))[0]
+        if "encoder.language_embedding.weight" not in sd:
+            lang_id = None  # InferenceToucanTTS.py:196-197
+        e = F.normalize(utt_emb.unsqueeze(0))[0] if utt_emb is not None else None
         enc = encoder(text, utt_emb, lang_id, sd, taps)
         p = predictor(enc, e, sd, "pitch_predictor", 7, 5) if pitch is None else pitch.reshape(-1).float()
         en = predictor(enc, e, sd, "energy_predictor", 2, 3) if energy is None else energy.reshape(-1).float()

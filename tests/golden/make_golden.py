@@ -103,10 +103,11 @@ def close(name, a, b, tol):
 
 
 class RefAcoustic:
-    def __init__(self, sd_np):
+    def __init__(self, sd_np, **model_kwargs):
+        """model_kwargs: e.g. lang_embs=None / utt_embed_dim=None for the checkpoint variants of ToucanTTSInterface.py:55-63."""
         from InferenceInterfaces.InferenceArchitectures.InferenceToucanTTS import ToucanTTS
         sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
-        self.m = ToucanTTS(weights=sd)  # strict load validates the fixture schema
+        self.m = ToucanTTS(weights=sd, **model_kwargs)  # strict load validates the fixture schema
         with torch.no_grad():
             self.m.store_inverse_all()
         self.m.eval()
