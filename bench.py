@@ -103,11 +103,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # Rehearsal on a one-GPU box (never used by the driver): TOUCAN_BENCH_REHEARSAL=1 maps every rank to device 0 and runs the
+    # collectives over gloo on host copies, so that the launch / barrier / max-over-ranks / rank-0 JSON logic can be exercised
+    # end to end without a second GPU.  The numbers of such a run mean nothing.
+    rehearsal = os.environ.get("TOUCAN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     bf16 = args.dtype == "bf16"
     log("building engines (fixture weights)")
@@ -123,7 +132,8 @@ def main():
     durs = [torch.full((L,), args.frames_per_phone, dtype=torch.int32, device=dev) for _ in ids]
     zs = [torch.from_numpy(syn.postflow_noise(u, T)).to(dev) for u in ids]
     langs = [syn.LANG_EN] * B
-    gathered = torch.empty(world, B * T * 384, device=dev) if world > 1 else None
+    # 1-D concatenation form of the gather output (accepted by every backend)
+    gathered = torch.empty(world * B * T * 384, device="cpu" if rehearsal else dev) if world > 1 else None
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
@@ -137,7 +147,8 @@ def main():
         if record:
             ev[2].record()
         if world > 1:  # one exchange step: waveforms of all ranks (equal length here) over RCCL/xGMI
-            dist.all_gather_into_tensor(gathered, wav[: B * T * 384].contiguous())
+            block = wav[: B * T * 384].contiguous()
+            dist.all_gather_into_tensor(gathered, block.cpu() if rehearsal else block)
         return out, wav
 
     # ---- warm-up; the first warm-up step times every conv class to find the dominant kernel ----
@@ -173,7 +184,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
