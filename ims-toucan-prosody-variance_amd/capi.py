@@ -86,12 +86,14 @@ PROTOTYPES = {
     "tts_glow_invconv_actnorm": (C.c_int, [_p, _i, _i, _i, _p, _p, _p, _p]),
     "tts_snake_aa": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p]),
     "tts_conv_post": (C.c_int, [_p, _i, _i, _p, _f, _i, _f, _p, _p, _i, _i, _i, _p]),
+    "tts_conv_post_snake_tile_rows": (C.c_int, []),
+    "tts_conv_post_snake": (C.c_int, [_p, _i, _i, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tts_gather_rows": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _p]),
     "tts_axpby": (C.c_int, [_p, _i, _f, _p, _i, _f, _p, _i, _i, _i, _p]),
 }
 
 _LIB = None
-ABI_VERSION = 5  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 6  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

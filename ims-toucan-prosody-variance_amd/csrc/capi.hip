@@ -24,6 +24,8 @@ int conv1d_small_tile_rows(int cout, int mode, int packed_cols);
 int layernorm(const float*, int, float*, int, const float*, const float*, int, int, float, hipStream_t);
 int cond_layernorm(const float*, int, float*, int, const float*, const float*, int, const TtsTile*, int, int, hipStream_t);
 long long cln_mlp_weight_floats(int, int);
+int conv_post_snake_tile_rows();
+int conv_post_snake(const float*, int, int, const float*, float, const float*, const float*, const float*, float*, const TtsTile*, int, int, int, hipStream_t);
 int cln_mlp(const float*, int, int, int, const float*, int, float*, hipStream_t);
 int l2_normalize(const float*, float*, int, int, hipStream_t);
 int groupnorm(const float*, int, float*, int, const float*, const float*, int, int, float, int, const float*, int, const int*,
@@ -150,6 +152,12 @@ int tts_snake_aa(const float* x, int32_t ldx, float* y, int32_t ldy, const float
   return tts::snake_aa(x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, io_flags, ST(stream));
 }
 
+int tts_conv_post_snake_tile_rows(void) { return tts::conv_post_snake_tile_rows(); }
+int tts_conv_post_snake(const float* x, int32_t ldx, int32_t cin, const float* w, float bias, const float* alpha, const float* beta,
+                        const float* filt, float* wav, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, int32_t io_flags,
+                        tts_stream_t stream) {
+  return tts::conv_post_snake(x, ldx, cin, w, bias, alpha, beta, filt, wav, tiles, n_tiles, tile_rows, io_flags, ST(stream));
+}
 int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w, float bias, int32_t pre_act, float pre_slope, float* wav,
                   const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, int32_t io_flags, tts_stream_t stream) {
   return tts::conv_post(x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, io_flags, ST(stream));

@@ -360,4 +360,67 @@ int conv_post(const float* x, int ldx, int cin, const float* w, float bias, int 
   return launch_status("conv_post");
 }
 
+// ------------------------------------------------------------------------------------------------
+// activation_post (anti-aliased snake) + output conv (32 -> 1, 7 taps) + tanh in one launch (InferenceBigVGAN.py:90-95).
+// 250 output samples per workgroup: the 256-row window (3 rows of conv halo each side) is 8 streamed groups of 32 frames x
+// 32 channels = one snake stream per thread, written to LDS as fp32 (zero outside the utterance = the conv's padding);
+// then thread r < 250 reduces its 7 x 32 patch.  Saves the 2 x 335 MB round trip of the activated tensor at batch 32.
+// ------------------------------------------------------------------------------------------------
+constexpr int CPS_TILE = 250, CPS_WIN = 256, CPS_C = 32;
+
+template <bool XB>
+__global__ __launch_bounds__(256) void conv_post_snake_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, float bias,
+                                                             const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                             const float* __restrict__ filt, float* __restrict__ wav,
+                                                             const TtsTile* __restrict__ tiles) {
+  __shared__ float xs[CPS_WIN * (CPS_C + 1)];
+  __shared__ float wsm[7 * CPS_C];
+  const TtsTile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (tid < 7 * CPS_C) wsm[tid] = w[tid];
+  const int T = t.seq_end - t.seq_begin;
+  const int ch = tid & 31, g = tid >> 5;
+  const int t0 = t.row0 - 3 + g * 32 - t.seq_begin;  // local frame of this thread's first window row
+  float f[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) f[k] = filt[k];
+  float* col = xs + (g * 32) * (CPS_C + 1) + ch;
+  if (t0 + 31 >= 0 && t0 < T) {
+    const float ea = expf(alpha[ch]), ib = 1.0f / (expf(beta[ch]) + 1e-9f);
+    const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(x);
+    snake_stream<4>([&](int q) { return XB ? bf16_to_f32(xh[(size_t)(t.seq_begin + q) * ldx + ch]) : x[(size_t)(t.seq_begin + q) * ldx + ch]; },
+                    [&](int i, float v) { col[i * (CPS_C + 1)] = (t0 + i >= 0 && t0 + i < T) ? v : 0.0f; }, T, t0, f, ea, ib);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) col[i * (CPS_C + 1)] = 0.0f;
+  }
+  __syncthreads();
+  const int row = t.row0 + tid;
+  if (tid >= CPS_TILE || row >= t.seq_end) return;
+  float a = bias;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const float* xr = xs + (tid + j) * (CPS_C + 1);
+    const float* wr = wsm + j * CPS_C;
+#pragma unroll
+    for (int c = 0; c < CPS_C; ++c) a = fmaf(xr[c], wr[c], a);
+  }
+  wav[row] = tanhf(a);
+}
+
+int conv_post_snake_tile_rows() { return CPS_TILE; }
+
+int conv_post_snake(const float* x, int ldx, int cin, const float* w, float bias, const float* alpha, const float* beta, const float* filt,
+                    float* wav, const TtsTile* tiles, int n_tiles, int tile_rows, int io_flags, hipStream_t st) {
+  TTS_CHECK_ARG(x && w && alpha && beta && filt && wav && tiles, "conv_post_snake: null pointer");
+  TTS_CHECK_ARG(cin == CPS_C, "conv_post_snake: cin must be %d, got %d", CPS_C, cin);
+  TTS_CHECK_ARG(tile_rows == CPS_TILE, "conv_post_snake: tile table must use %d rows, got %d", CPS_TILE, tile_rows);
+  if (n_tiles == 0) return TTS_OK;
+  if (io_flags & TTS_IO_X_BF16)
+    hipLaunchKernelGGL(conv_post_snake_kernel<true>, dim3(n_tiles), dim3(256), 0, st, x, ldx, w, bias, alpha, beta, filt, wav, tiles);
+  else
+    hipLaunchKernelGGL(conv_post_snake_kernel<false>, dim3(n_tiles), dim3(256), 0, st, x, ldx, w, bias, alpha, beta, filt, wav, tiles);
+  return launch_status("conv_post_snake");
+}
+
 }  // namespace tts

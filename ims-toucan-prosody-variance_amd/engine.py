@@ -208,6 +208,14 @@ class Ops:
                                           256, capi.IO_X_BF16 if _is_bf16(x) else 0, self.stream()), "tts_conv_post")
         return wav
 
+    def conv_post_snake(self, x, cin, w, bias, alpha, beta, filt, wav, rag):
+        tr = self.lib.tts_conv_post_snake_tile_rows()
+        tiles, n = rag.tiles(tr)
+        capi.check(self.lib.tts_conv_post_snake(x.data_ptr(), _ld(x), cin, w.data_ptr(), bias, alpha.data_ptr(), beta.data_ptr(), filt.data_ptr(),
+                                                wav.data_ptr(), tiles.data_ptr(), n, tr, capi.IO_X_BF16 if _is_bf16(x) else 0, self.stream()),
+                   "tts_conv_post_snake")
+        return wav
+
     def gather_rows(self, src, idx, dst):
         capi.check(self.lib.tts_gather_rows(src.data_ptr(), _ld(src), idx.data_ptr(), dst.data_ptr(), _ld(dst), idx.numel(), src.shape[1],
                                             self.stream()), "tts_gather_rows")
@@ -750,8 +758,8 @@ class VocoderEngine:
                 taps[f"voc_stage{i}"] = x.float()
         wav = ops.empty(R)
         if big:
-            t = ops.snake_aa(x, ops.empty(R, ch, dtype=x.dtype), *self.post_snake, self.filt, ch, rag)
-            ops.conv_post(t, ch, self.post_w, self.post_b, PRE_NONE, 0.0, wav, rag)
+            # activation_post + conv_post + tanh in one launch: the activated [R, 32] tensor never reaches HBM
+            ops.conv_post_snake(x, ch, self.post_w, self.post_b, *self.post_snake, self.filt, wav, rag)
         else:
             ops.conv_post(x, ch, self.post_w, self.post_b, PRE_LRELU, 0.01, wav, rag)  # InferenceAvocodo.py:53
         return wav, rag

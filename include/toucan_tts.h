@@ -205,6 +205,14 @@ int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w /*[7]
                   float pre_slope, float* wav, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
                   int32_t io_flags /* TTS_IO_X_BF16 */, tts_stream_t stream);
 
+/* BigVGAN's last two ops in one launch: anti-aliased SnakeBeta (activation_post) then the 7-tap output conv + tanh
+ * (InferenceBigVGAN.py:90-95).  The activated tensor exists only in LDS.  cin must be 32; tile_rows must be
+ * tts_conv_post_snake_tile_rows() (250: a 256-row window = 8 streamed groups of 32 frames per channel). */
+int tts_conv_post_snake_tile_rows(void);
+int tts_conv_post_snake(const float* x, int32_t ldx, int32_t cin, const float* w /*[7][cin]*/, float bias, const float* alpha,
+                        const float* beta, const float* filt /*[12]*/, float* wav, const TtsTile* tiles, int32_t n_tiles,
+                        int32_t tile_rows, int32_t io_flags /* TTS_IO_X_BF16 */, tts_stream_t stream);
+
 /* Elementwise helper: y = a*x + b*z (z may be NULL), rows x c with strides. */
 int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz, float b, float* y, int32_t ldy,
               int32_t rows, int32_t c, tts_stream_t stream);
@@ -216,7 +224,7 @@ int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float*
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 5
+#define TTS_ABI_VERSION 6
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -408,6 +408,22 @@ class Emulator:
             _arr(wav, se)[sb:se] = np.tanh(a).astype(np.float32)
         return 0
 
+    def tts_conv_post_snake_tile_rows(self):
+        return 250
+
+    def tts_conv_post_snake(self, x, ldx, cin, w, bias, alpha, beta, filt, wav, tiles, n_tiles, tile_rows, io_flags, stream):
+        self._count("conv_post_snake")
+        W = _mat(w, 7, cin, cin).astype(np.float64)
+        for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
+            n = se - sb
+            X = _load(x, sb, se, cin, ldx, io_flags & capi.IO_X_BF16).astype(np.float64)
+            X = _snake_seq(X, _arr(alpha, cin), _arr(beta, cin), _arr(filt, 12))
+            xp = np.zeros((n + 6, cin))
+            xp[3:3 + n] = X
+            a = bias + sum((xp[j:j + n] * W[j]).sum(1) for j in range(7))
+            _arr(wav, se)[sb:se] = np.tanh(a).astype(np.float32)
+        return 0
+
     def tts_gather_rows(self, src, ld_src, idx, dst, ld_dst, n, c, stream):
         self._count("gather_rows")
         ii = _arr(idx, n, np.int32)

@@ -415,3 +415,21 @@ def test_conv1d_rows_kernel_bf16_input(gpu, cpu, cin, cout, mode, lengths, pre, 
     finally:
         gpu.small_tile_blocks = 1536
     close(g, c, 2e-2)
+
+
+@pytest.mark.parametrize("lengths", [[1000, 9, 257], [250], [251, 1, 2, 499]])
+@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16])
+def test_conv_post_snake(gpu, cpu, lengths, store):
+    """activation_post (anti-aliased snake) + output conv + tanh fused (BigVGAN's last two ops) vs the fp64 emulator."""
+    c = 32
+    filt = torch.from_numpy(packing.kaiser_sinc_filter12())
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device)
+        x = to(rnd(rag.total_rows, c, seed=1)).to(store)
+        wav = to(torch.full((rag.total_rows,), 9.0))
+        return ops.conv_post_snake(x, c, to(rnd(7, c, seed=2, scale=0.1)), 0.05, to(rnd(c, seed=3, scale=0.3)), to(rnd(c, seed=4, scale=0.3)),
+                                   to(filt), wav, rag)
+
+    g, cc = both(gpu, cpu, run)
+    close(g, cc, 2e-5)
