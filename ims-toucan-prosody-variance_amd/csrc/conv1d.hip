@@ -15,6 +15,11 @@
 // LDS layout: activations [rows][32+1] floats (odd pitch -> the A-fragment column read, 32 lanes on 32
 // consecutive rows, hits 32 distinct banks); weights [32][BN] floats (B-fragment read is a contiguous row).
 //
+// Tile forms (conv1d_dispatch): 128x128 / 128x96 / 128x64 / 256x32 by output width ("regular"); 64x64 and 64x128 tiles with a
+// double-buffered, register-prefetched window when the host asks for 64-row tiles ("small-batch form": grids that would
+// leave the chip idle); and gemm_rows_kernel, an LDS-free operand stream for 1-tap convs in the small-batch form.  All share
+// conv_epilogue (bias, per-utterance vector, pre-add, activation, GLU / gated / coupling, residual, accumulate, bf16 I/O).
+//
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
 #include <cstdlib>
 
