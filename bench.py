@@ -1,37 +1,74 @@
 """bench.py - throughput of the ToucanTTS hot path on MI355X (metric of BASELINE.json).
 
 One step = one pass of the hot path over one batch of synthetic utterances per GPU:
-acoustic model (Conformer enc -> predictors bypassed by gold durations -> length regulator -> Conformer dec
--> PostNet -> PostFlow) + BigVGAN vocoder, batch 32 x 128 phonemes per GPU (BASELINE.json configs[2]; at N
-GPUs the job is N x 32 utterances, weak scaling, waveforms all-gathered over RCCL).  Inputs are resident in
-HBM before the timed region.  Prints ONE JSON line on rank 0.
+acoustic model (Conformer enc -> pitch / energy predictors -> control -> length regulator -> Conformer dec -> PostNet
+-> PostFlow) + BigVGAN vocoder, batch 32 x 128 phonemes per GPU (BASELINE.json configs[2]; at N GPUs the job is N x 32
+utterances, weak scaling, waveforms all-gathered over RCCL).  Gold durations fix the frame count (the duration predictor is
+bypassed: with random-init weights its exp() output is numerically wild, SURVEY.md fact 4 - the API offers `durations=` for
+exactly this, ToucanTTSInterface.py:139-141).  Inputs are resident in HBM before the timed region; the PCIe-inclusive rate
+(host phoneme tensors in, host waveforms out) is measured separately after it and reported beside `value`, never as `value`.
+Prints ONE JSON line on rank 0.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--phones 128] [--vocoder bigvgan|hifigan]
-                    [--dtype fp32|bf16] [--no-cpu-baseline]
+                    [--dtype fp32|bf16|fp16] [--pitch-scale S] [--energy-scale S] [--no-cpu-baseline]
+
+  --dtype bf16 (default)                                    BASELINE.json configs[2]
+  --dtype fp16 --pitch-scale 1.3 --energy-scale 0.7         the per-GPU shard of configs[4] (fp16 MFMA, PostFlow on, variance scaling)
+  --gpus N (N > 1) without a torch.distributed environment  re-launches itself under `python -m torch.distributed.run`
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_16BIT_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (6.3 TB/s is what a streaming copy reaches)
+PEAK_VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # lane-operations/s: 256 CUs x 4 SIMD-32 at 2.4 GHz (one wave64 instruction = 2 cycles)
 
-import ims_toucan_prosody_variance_amd  # noqa: E402,F401
-from ims_toucan_prosody_variance_amd import engine, fixture_weights as fw, profiling, synthetic as syn  # noqa: E402
 
-PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--phones", type=int, default=128)
+    ap.add_argument("--frames-per-phone", type=int, default=5)
+    ap.add_argument("--vocoder", default="bigvgan", choices=["bigvgan", "hifigan"])
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16"],
+                    help="bf16 = BASELINE.json configs[2] (bf16 MFMA GEMMs, fp32 statistics); fp16 = configs[4]'s fp16 MFMA path; "
+                         "fp32 = exact-parity configuration")
+    ap.add_argument("--pitch-scale", type=float, default=1.0, help="pitch_variance_scale (configs[4]: 1.3)")
+    ap.add_argument("--energy-scale", type=float, default=1.0, help="energy_variance_scale (configs[4]: 0.7)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
+    ap.add_argument("--graphs", action="store_true", help="replay the shape-static stages as HIP graphs (no per-kernel roofline leg)")
+    return ap.parse_args()
+
+
+def relaunch_distributed(args):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as a child job (one process per GPU over RCCL) and
+    exit with its code.  Nothing in this process has touched the GPU yet (no torch.cuda call, no HIP library loaded)."""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(phones, frames_per_phone, vocoder):
     """The CPU oracle (kind 'port') on a bounded sample: ONE utterance of the same workload, processed the way the
     reference's read_to_file does (one utterance at a time), all host cores."""
+    import numpy as np
+    import torch
+    from ims_toucan_prosody_variance_amd import fixture_weights as fw, synthetic as syn
     from oracle import toucan_oracle as orc
     # the GPU box exposes many more logical CPUs than its cgroup share (16 per GPU): oversubscribing stalls torch
     try:
@@ -66,17 +103,28 @@ def cpu_baseline(phones, frames_per_phone, vocoder):
                 e2e_rtf=(ta + tv) / (w.numel() / 24000.0))
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_pmc_resblock_traffic.json:
-    FETCH_SIZE and WRITE_SIZE in separate --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  None if not collected."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_resblock_traffic.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        rows = [r for r in json.load(f)["launches"] if r["kernel"] == kernel and r["act"] == "snake"]
-    if not rows:
-        return None
-    return sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
+def committed_counters(kernel):
+    """HBM bytes per launch and VALU lane-operations per element of `kernel` from this round's committed rocprofv3 PMC passes
+    (separate --pmc runs over tools/microbench_resblock.py at the bench's shapes; FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    Counter passes cannot share a process with the timed region, so these are read from profiles/; the file is named in the
+    line.  (None, None, None) when no pass covers the kernel."""
+    for tag in ("r02", "r01_v18", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_resblock_traffic.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rows = [r for r in json.load(f)["launches"] if r["kernel"] == kernel and r["act"] == "snake"]
+        if not rows:
+            continue
+        traffic = sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
+        valu = None
+        sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_resblock_SQ_summary.json")
+        if os.path.exists(sq):
+            with open(sq) as f:
+                v = [r["valu_per_elem"] for r in json.load(f)["launches"] if r["kernel"] == kernel and r["act"] == "snake"]
+            valu = sum(v) / len(v) if v else None
+        return traffic, valu, os.path.relpath(path, ROOT)
+    return None, None, None
 
 
 def log(msg):
@@ -85,24 +133,21 @@ def log(msg):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
-    ap.add_argument("--phones", type=int, default=128)
-    ap.add_argument("--frames-per-phone", type=int, default=5)
-    ap.add_argument("--vocoder", default="bigvgan", choices=["bigvgan", "hifigan"])
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16"],
-                    help="bf16 = BASELINE.json configs[2] (bf16 MFMA GEMMs, fp32 statistics); fp32 = exact-parity configuration")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_distributed(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ims_toucan_prosody_variance_amd  # noqa: F401
+    from ims_toucan_prosody_variance_amd import capi, engine, fixture_weights as fw, profiling, synthetic as syn
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # Rehearsal on a one-GPU box (never used by the driver): TOUCAN_BENCH_REHEARSAL=1 maps every rank to device 0 and runs the
     # collectives over gloo on host copies, so that the launch / barrier / max-over-ranks / rank-0 JSON logic can be exercised
     # end to end without a second GPU.  The numbers of such a run mean nothing.
@@ -118,29 +163,33 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    bf16 = args.dtype == "bf16"
-    log("building engines (fixture weights)")
-    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, bf16=bf16)
+    precision = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype]
+    log(f"building engines (fixture weights, {precision})")
+    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, precision=precision, use_graphs=args.graphs)
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
-    voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, bf16=bf16, fuse_snake=args.fuse_snake)
+    voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, precision=precision, fuse_snake=args.fuse_snake, use_graphs=args.graphs)
 
     B, L, T = args.batch, args.phones, args.phones * args.frames_per_phone
     log(f"synthetic inputs: {B} x {L} phonemes -> {T} frames per utterance")
     ids = [rank * B + u for u in range(B)]
-    texts = [torch.from_numpy(syn.utterance_features(u, L, word_boundaries=False)).to(dev) for u in ids]
-    embs = torch.from_numpy(np.stack([syn.utterance_embedding(u) for u in ids])).to(dev)
+    host_texts = [torch.from_numpy(syn.utterance_features(u, L, word_boundaries=False)).pin_memory() for u in ids]
+    host_embs = torch.from_numpy(np.stack([syn.utterance_embedding(u) for u in ids])).pin_memory()
+    host_zs = [torch.from_numpy(syn.postflow_noise(u, T)).pin_memory() for u in ids]
+    texts = [t.to(dev) for t in host_texts]
+    embs = host_embs.to(dev)
     durs = [torch.full((L,), args.frames_per_phone, dtype=torch.int32, device=dev) for _ in ids]
-    zs = [torch.from_numpy(syn.postflow_noise(u, T)).to(dev) for u in ids]
+    zs = [z.to(dev) for z in host_zs]
     langs = [syn.LANG_EN] * B
+    scales = dict(pitch_variance_scale=args.pitch_scale, energy_variance_scale=args.energy_scale)
     # 1-D concatenation form of the gather output (accepted by every backend)
     gathered = torch.empty(world * B * T * 384, device="cpu" if rehearsal else dev) if world > 1 else None
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 
-    def step(record=False):
+    def step(record=False, tx=texts, em=embs, zz=zs):
         if record:
             ev[0].record()
-        out = ac.forward(texts, embs, langs, durations=durs, z_noise=zs)
+        out = ac.forward(tx, em, langs, durations=durs, z_noise=zz, **scales)
         if record:
             ev[1].record()
         wav, rag = voc.forward(out["mel_packed"], out["rag_mel"])
@@ -151,22 +200,29 @@ def main():
             dist.all_gather_into_tensor(gathered, block.cpu() if rehearsal else block)
         return out, wav
 
-    # ---- warm-up; the first warm-up step times every conv class to find the dominant kernel ----
+    # ---- warm-up; the second warm-up step times every MFMA kernel class to find the dominant one ----
     log("warm-up step 1 (untimed: first-launch costs)")
     step()
     torch.cuda.synchronize()
-    timer = profiling.ConvTimer()
-    ac.ops.timer = voc.ops.timer = timer
-    log("warm-up step 2 (all MFMA kernel classes timed)")
-    step()
-    torch.cuda.synchronize()
-    classes = timer.summary()
-    dominant = max(classes, key=lambda k: classes[k]["total_ms"])
-    ac.ops.timer = voc.ops.timer = None
+    classes, dominant = {}, None
+    if not args.graphs:
+        timer = profiling.ConvTimer()
+        ac.ops.timer = voc.ops.timer = timer
+        log("warm-up step 2 (all MFMA kernel classes timed)")
+        calls0 = capi.CALLS
+        step()
+        torch.cuda.synchronize()
+        abi_calls = capi.CALLS - calls0
+        classes = timer.summary()
+        dominant = max(classes, key=lambda k: classes[k]["total_ms"]) if classes else None
+        ac.ops.timer = voc.ops.timer = None
+    else:
+        abi_calls = None
+        step()
     for _ in range(max(0, args.warmup - 2)):
         step()
     # ---- timed region: only the dominant class carries event pairs (a few dozen launches per step) ----
-    timer = profiling.ConvTimer(select={dominant})
+    timer = profiling.ConvTimer(select={dominant}) if dominant else None
     ac.ops.timer = voc.ops.timer = timer
     torch.cuda.synchronize()
     if world > 1:
@@ -187,12 +243,59 @@ def main():
         tt = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    ac.ops.timer = voc.ops.timer = None
 
     frames_out = int(sum(m.shape[0] for m in out["mel"]))
     audio_s = frames_out * 384 / 24000.0
-    dom = timer.summary()[dominant]
-    peak = PEAK_BF16_TFLOPS if ("bf16" in dominant or "resblock" in dominant) else PEAK_F32_TFLOPS
+
+    # ---- PCIe-inclusive rate (SURVEY.md 8(d) protocol): phoneme tensors / embeddings / noise from pinned host memory in,
+    #      waveforms to pinned host memory out, every step; reported beside `value` ----
+    pcie = None
+    if world == 1:
+        host_wav = torch.empty(wav.numel(), dtype=torch.float32).pin_memory()
+        n_pcie = max(2, min(args.steps, 3))
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for _ in range(n_pcie):
+            tx = [t.to(dev, non_blocking=True) for t in host_texts]
+            em = host_embs.to(dev, non_blocking=True)
+            zz = [z.to(dev, non_blocking=True) for z in host_zs]
+            _, w = step(tx=tx, em=em, zz=zz)
+            host_wav.copy_(w, non_blocking=True)
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - tp0) / n_pcie
+        pcie = {"value": frames_out / tp, "unit": "mel-frames/s", "ms_per_step": 1e3 * tp, "steps": n_pcie,
+                "h2d_bytes": int(sum(t.numel() for t in host_texts) * 4 + host_embs.numel() * 4 + sum(z.numel() for z in host_zs) * 4),
+                "d2h_bytes": int(wav.numel() * 4)}
+
     if rank == 0:
+        roof = None
+        if dominant:
+            dom = timer.summary()[dominant]
+            is16 = ("bf16" in dominant or "f16" in dominant or "resblock" in dominant) and "f32" not in dominant
+            peak = PEAK_16BIT_TFLOPS if is16 else PEAK_F32_TFLOPS
+            traffic, valu_per_elem, src = committed_counters(dominant)
+            mfma_frac = dom["tflops"] / peak
+            gbs = dom["bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9
+            hbm_frac = gbs / PEAK_HBM_GBS
+            valu_frac = None
+            if valu_per_elem is not None and dom.get("elems_per_launch"):
+                valu_frac = valu_per_elem * dom["elems_per_launch"] / (dom["avg_us"] * 1e-6) / PEAK_VALU_LANE_OPS
+            # the binding resource is the one with the highest utilisation (SQ counters for the fused step: VALU issue, not
+            # the matrix pipe and not HBM - DESIGN.md section 5); `frac` / `achieved` / `peak` describe THAT resource's roofline
+            # among the two the contract names, the other fraction and the VALU view are given next to it
+            bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
+            roof = {"bound": bound, "kernel": dominant,
+                    "achieved": dom["tflops"] if bound == "mfma" else gbs, "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
+                    "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": max(mfma_frac, hbm_frac),
+                    "mfma_frac": mfma_frac, "mfma_tflops": dom["tflops"], "mfma_peak_tflops": peak,
+                    "hbm_frac": hbm_frac, "hbm_gbs_algorithmic": gbs, "hbm_peak_gbs": PEAK_HBM_GBS,
+                    "valu_frac": valu_frac, "valu_lane_ops_per_element": valu_per_elem,
+                    "limiter": ("valu-issue" if valu_frac is not None and valu_frac > max(mfma_frac, hbm_frac) else bound),
+                    "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                    "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / args.steps,
+                    "flops_per_launch": dom["flops_per_launch"], "share_of_step": dom["total_ms"] / (1e3 * elapsed)}
+        cfg_name = "configs[2]" if args.dtype == "bf16" else ("configs[4] (per-GPU shard)" if args.dtype == "fp16" else "configs[2] shape in fp32")
         line = {
             "metric": "mel-frames/sec + vocoder RTF @24kHz, batch=32, 1/2/4/8 MI355X",
             "value": world * frames_out * args.steps / elapsed,
@@ -200,18 +303,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"configs[2]: batch={B}/GPU x {L} phonemes -> {T} frames, acoustic (PostFlow on) + {args.vocoder}, "
-                                   f"gold durations {args.frames_per_phone}/phoneme, fixture weights",
+            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
+            "config": {"workload": f"{cfg_name}: batch={B}/GPU x {L} phonemes -> {T} frames, acoustic (PostFlow on) + {args.vocoder}, "
+                                   f"gold durations {args.frames_per_phone}/phoneme (duration predictor bypassed; pitch / energy predicted), "
+                                   f"pitch scale {args.pitch_scale}, energy scale {args.energy_scale}, fixture weights",
                        "global_batch": world * B, "phones": L, "frames_per_utt": frames_out // B, "vocoder": args.vocoder,
-                       "acoustic_dtype": "bf16 MFMA / f32 activations" if bf16 else "f32", "vocoder_dtype": "bf16" if bf16 else "f32", "parallelism": f"dp{world}"},
+                       "acoustic_dtype": f"{args.dtype} MFMA / f32 activations" if args.dtype != "fp32" else "f32",
+                       "vocoder_dtype": args.dtype if args.dtype != "fp32" else "f32", "parallelism": f"dp{world}",
+                       "hip_graphs": bool(args.graphs)},
             "acoustic_mel_frames_per_s": world * frames_out * args.steps / t_ac,
             "vocoder_rtf": t_voc / (args.steps * audio_s),
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),
-            "roofline": {"bound": "mfma", "kernel": dominant, "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": dom["tflops"] / peak, "traffic": pmc_traffic(dominant), "avg_launch_us": dom["avg_us"],
-                         "launches_per_step": dom["launches"] / args.steps, "flops_per_launch": dom["flops_per_launch"],
-                         "share_of_step": dom["total_ms"] / (1e3 * elapsed)},
+            "abi_calls_per_step": abi_calls,
+            "pcie_inclusive": pcie,
+            "roofline": roof,
             "kernel_classes_warmup_step": {k: {"ms": round(v["total_ms"], 3), "launches": v["launches"], "tflops": round(v["tflops"], 2)}
                                           for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["total_ms"])},
         }

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("TOUCAN_HIP_LIB") or os.path.join(_PKG, "libtoucan_hip
 MODE_LINEAR, MODE_GLU, MODE_GATED, MODE_COUPLING = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 PRE_NONE, PRE_LRELU, PRE_SNAKE = 0, 1, 2
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
 
 _p = C.c_void_p
 _i = C.c_int32
@@ -56,10 +56,11 @@ class TtsResblockDesc(C.Structure):
         ("alpha", _f), ("res_scale", _f), ("accumulate", _i),
         ("io_bf16", _i),
         ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
+        ("compute", _i),
     ]
 
 
-IO_X_BF16, IO_Y_BF16, IO_RES_BF16 = 1, 2, 4
+IO_X_BF16, IO_Y_BF16, IO_RES_BF16, IO_F16 = 1, 2, 4, 8
 
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
 PROTOTYPES = {
@@ -93,7 +94,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 6  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 7  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):
@@ -139,7 +140,12 @@ def _assert_single_hip_runtime():
         raise ToucanHipError(f"two HIP runtimes are mapped ({sorted(paths)}); import torch before loading libtoucan_hip.so")
 
 
+CALLS = 0  # ABI calls checked so far (bench.py reports the calls of one pass)
+
+
 def check(rc, what=""):
+    global CALLS
+    CALLS += 1
     if rc != 0:
         msg = lib().tts_last_error().decode("utf-8", "replace")
         raise ToucanHipError(f"{what} failed with code {rc}: {msg}")

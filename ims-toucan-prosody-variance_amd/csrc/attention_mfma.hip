@@ -188,11 +188,8 @@ int relpos_attention_mfma(const float* qkv, int ld_qkv, const float* ptab, int p
   TTS_CHECK_ARG((ld_ctx & 3) == 0 && ((uintptr_t)ctx & 15) == 0, "relpos_attention: ctx alignment");
   if (n_tiles == 0) return TTS_OK;
   const size_t lds = (size_t)(2 * AM_KT * AM_PITCH + (AM_PW + 1) * AM_PITCH + 4 * 64 * AM_GP) * sizeof(float);
-  static bool lds_raised = false;
-  if (!lds_raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(relpos_attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_raised = true;
-  }
+  static unsigned long long lds_raised = 0;  // per device (common.h)
+  if (lds > 64 * 1024) (void)raise_lds_limit(reinterpret_cast<const void*>(relpos_attention_mfma_kernel), lds_raised);
   hipLaunchKernelGGL(relpos_attention_mfma_kernel, dim3(n_tiles, heads), dim3(256), lds, st, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx,
                      ld_ctx, heads, tiles);
   return launch_status("relpos_attention(mfma)");

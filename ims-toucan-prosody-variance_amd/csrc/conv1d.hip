@@ -43,12 +43,10 @@ __device__ __forceinline__ unsigned short f2bf(float f) { return f32_to_bf16(f);
 
 // One 4-channel group into the LDS window: the bf16 window takes it as ONE 8-byte store (rows are 16-byte aligned and the group
 // starts at a multiple of 4 channels) - four 2-byte stores per group made the staging pass as long as the MFMAs it feeds.
-template <bool BF16, class T>
+template <bool BF16, bool F16, class T>
 __device__ __forceinline__ void store_group(T* dst, float a, float b, float c, float e) {
   if constexpr (BF16) {
-    const unsigned int lo = (unsigned int)f32_to_bf16(a) | ((unsigned int)f32_to_bf16(b) << 16);
-    const unsigned int hi = (unsigned int)f32_to_bf16(c) | ((unsigned int)f32_to_bf16(e) << 16);
-    *reinterpret_cast<uint2*>(dst) = make_uint2(lo, hi);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack16<F16>(a, b), pack16<F16>(c, e));
   } else {
     dst[0] = a;
     dst[1] = b;
@@ -57,17 +55,15 @@ __device__ __forceinline__ void store_group(T* dst, float a, float b, float c, f
   }
 }
 
-template <bool BF16>
-struct Elem;
-template <>
-struct Elem<false> {
+template <bool BF16, bool F16>
+struct Elem {
+  using T = unsigned short;
+  static __device__ __forceinline__ unsigned short cvt(float v) { return to16<F16>(v); }
+};
+template <bool F16>
+struct Elem<false, F16> {
   using T = float;
   static __device__ __forceinline__ float cvt(float v) { return v; }
-};
-template <>
-struct Elem<true> {
-  using T = unsigned short;
-  static __device__ __forceinline__ unsigned short cvt(float v) { return f2bf(v); }
 };
 
 // Fused epilogue shared by the conv kernels; C/D layout of a 32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
@@ -75,6 +71,7 @@ struct Elem<true> {
 template <int TM, int TN, int NH, bool DUAL>
 __device__ __forceinline__ void conv_epilogue(const TtsConvDesc& d, const TtsTile& tile, int n0, int wm, int wn, int lrow, int lk,
                                               const f32x16 (&acc)[NH][TM][TN]) {
+  const bool io_f16 = d.io_flags & TTS_IO_F16;  // format of the 16-bit tensors of this call (else bf16)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -106,14 +103,14 @@ __device__ __forceinline__ void conv_epilogue(const TtsConvDesc& d, const TtsTil
         }
         v *= d.alpha;
         if (d.res) {
-          const float rv = (d.io_flags & TTS_IO_RES_BF16) ? bf16_to_f32(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n])
+          const float rv = (d.io_flags & TTS_IO_RES_BF16) ? load16(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n], io_f16)
                                                           : d.res[(size_t)row * d.ld_res + n];
           v += d.res_scale * rv;
         }
         if (d.io_flags & TTS_IO_Y_BF16) {
           unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
-          if (d.accumulate) v += bf16_to_f32(*yp);
-          *yp = f32_to_bf16(v);
+          if (d.accumulate) v += load16(*yp, io_f16);
+          *yp = store16(v, io_f16);
         } else {
           float* yp = d.y + (size_t)row * d.ldy + n;
           if (d.accumulate) v += *yp;
@@ -129,10 +126,11 @@ __device__ __forceinline__ void conv_epilogue(const TtsConvDesc& d, const TtsTil
 // step s, so its global/L2 latency hides under the matrix work; one barrier per step, one more per slab for the
 // activation window.  bf16 uses 64-channel slabs (4 k-steps of v_mfma_f32_32x32x16_bf16 per tap), fp32 32-channel
 // slabs (16 k-steps of v_mfma_f32_32x32x2_f32); either way a weight slab is BN*16/32 KiB.
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE>
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16>
 __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
+  static_assert(BF16 || !F16, "F16 selects the element format of the 16-bit MFMA path");
   using C = ConvCfg<TM, TN, WAVES_M, WAVES_N, DUAL>;
-  using ET = typename Elem<BF16>::T;
+  using ET = typename Elem<BF16, F16>::T;
   constexpr int BM = C::BM, BN = C::BN;
   constexpr int NH = DUAL ? 2 : 1;
   constexpr int BK = BF16 ? 64 : 32;                // channels per slab
@@ -179,8 +177,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
 
   const int row_first = tile.row0 - d.pad_left;  // packed row of window row 0
-  const bool x_bf16 = d.io_flags & TTS_IO_X_BF16;
-  const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // the input viewed as bf16
+  const bool x_bf16 = d.io_flags & TTS_IO_X_BF16;  // x is a 16-bit tensor ...
+  const bool x_f16 = BF16 ? F16 : (d.io_flags & TTS_IO_F16) != 0;  // ... of this format (a 16-bit kernel only meets its own)
+  const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // the input viewed as 16-bit elements
   const bool vec_ok = ((d.ldx & 3) == 0) && ((d.cin & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.x) & (x_bf16 ? 7 : 15)) == 0);
   const bool win2 = WIN2 && vec_ok && win_rows * GPR <= PF * 256;  // else: one window, staged synchronously
   const ET* __restrict__ W = reinterpret_cast<const ET*>(d.w);
@@ -274,13 +273,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           win_decode(e, c0, wr, c4, ok, goff);
           float4 v;
           if (x_bf16)
-            v = make_float4(bf16_to_f32(pre[q].x & 0xFFFF), bf16_to_f32(pre[q].x >> 16), bf16_to_f32(pre[q].y & 0xFFFF), bf16_to_f32(pre[q].y >> 16));
+            v = make_float4(load16(pre[q].x & 0xFFFF, x_f16), load16(pre[q].x >> 16, x_f16), load16(pre[q].y & 0xFFFF, x_f16), load16(pre[q].y >> 16, x_f16));
           else
             v = make_float4(__builtin_bit_cast(float, pre[q].x), __builtin_bit_cast(float, pre[q].y), __builtin_bit_cast(float, pre[q].z),
                             __builtin_bit_cast(float, pre[q].w));
           if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
           ET* dst = xs + wr * XP + c4;
-          store_group<BF16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
+          store_group<BF16, F16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
                             pre_activation(v.z, d.pre_act, d.pre_slope), pre_activation(v.w, d.pre_act, d.pre_slope));
         }
       }
@@ -324,13 +323,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           if (live) {
             const float ea = expf(d.snake_alpha[cg]), ib = 1.0f / (expf(d.snake_beta[cg]) + 1e-9f);
             if (x_bf16)
-              snake_rows_fn<8>([&](int q) { return bf16_to_f32(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, T, t0, f, ea, ib, o);
+              snake_rows_fn<8>([&](int q) { return load16(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg], x_f16); }, T, t0, f, ea, ib, o);
             else
               snake_rows<8>(d.x, d.ldx, cg, tile.seq_begin, T, t0, f, ea, ib, o);
           }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (wr0 + i < win_rows) xs[(wr0 + i) * XP + chl] = Elem<BF16>::cvt((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
+          if (wr0 + i < win_rows) xs[(wr0 + i) * XP + chl] = Elem<BF16, F16>::cvt((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
       }
     } else if (vec_ok) {
       // PER independent 16-byte loads per thread are issued back to back (clamped addresses, no branches) before any of
@@ -371,13 +370,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           const int wr = e / q4, c4 = (e % q4) * 4;
           float4 v;
           if (x_bf16)
-            v = make_float4(bf16_to_f32(raw[p].x & 0xFFFF), bf16_to_f32(raw[p].x >> 16), bf16_to_f32(raw[p].y & 0xFFFF), bf16_to_f32(raw[p].y >> 16));
+            v = make_float4(load16(raw[p].x & 0xFFFF, x_f16), load16(raw[p].x >> 16, x_f16), load16(raw[p].y & 0xFFFF, x_f16), load16(raw[p].y >> 16, x_f16));
           else
             v = make_float4(__builtin_bit_cast(float, raw[p].x), __builtin_bit_cast(float, raw[p].y), __builtin_bit_cast(float, raw[p].z),
                             __builtin_bit_cast(float, raw[p].w));
           if (!okv[p]) v = make_float4(0.f, 0.f, 0.f, 0.f);
           ET* dst = xs + wr * XP + c4;
-          store_group<BF16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
+          store_group<BF16, F16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
                             pre_activation(v.z, d.pre_act, d.pre_slope), pre_activation(v.w, d.pre_act, d.pre_slope));
         }
       }
@@ -387,8 +386,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         const int gr = row_first + wr;
         float v = 0.f;
         if (gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c) < d.cin)
-          v = x_bf16 ? bf16_to_f32(xh[(size_t)gr * d.ldx + c0 + c]) : d.x[(size_t)gr * d.ldx + c0 + c];
-        xs[wr * XP + c] = Elem<BF16>::cvt(pre_activation(v, d.pre_act, d.pre_slope));
+          v = x_bf16 ? load16(xh[(size_t)gr * d.ldx + c0 + c], x_f16) : d.x[(size_t)gr * d.ldx + c0 + c];
+        xs[wr * XP + c] = Elem<BF16, F16>::cvt(pre_activation(v, d.pre_act, d.pre_slope));
       }
     }
     for (int tap = 0; tap < d.taps; ++tap, ++step) {
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j)
-                acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[h][i][j], 0, 0, 0);
+                acc[h][i][j] = mfma16<F16>(a[i], b[j], acc[h][i][j]);
           }
         }
       } else {
@@ -464,7 +463,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 //   fp32: v_mfma_f32_32x32x2_f32 takes k = lane>>5 of a k-pair; the k order inside a group of 8 channels is permuted so that
 //         one float4 of A per lane feeds four MFMAs (MFMA j of group g contracts channels 8g + j and 8g + 4 + j).
 // ------------------------------------------------------------------------------------------------
-template <bool DUAL, bool BF16, bool XB>
+template <bool DUAL, bool BF16, bool XB, bool F16>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
   constexpr int NH = DUAL ? 2 : 1;
   constexpr int DEPTH = 4;  // k-steps (bf16: 16 channels, fp32: 8 channels) in flight per wavefront
@@ -527,16 +526,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
           if (d.pre_act == TTS_PRE_LRELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              ap[q] = (unsigned int)f32_to_bf16(pre_activation(bf16_to_f32(a0[u][q] & 0xFFFF), d.pre_act, d.pre_slope)) |
-                      ((unsigned int)f32_to_bf16(pre_activation(bf16_to_f32(a0[u][q] >> 16), d.pre_act, d.pre_slope)) << 16);
+              ap[q] = pack16<F16>(pre_activation(from16<F16>(a0[u][q] & 0xFFFF), d.pre_act, d.pre_slope),
+                                  pre_activation(from16<F16>(a0[u][q] >> 16), d.pre_act, d.pre_slope));
           }
         } else {
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
-            ap[q] = (unsigned int)f32_to_bf16(pre_activation(u2f(a0[u][2 * q]), d.pre_act, d.pre_slope)) |
-                    ((unsigned int)f32_to_bf16(pre_activation(u2f(a0[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
-            ap[2 + q] = (unsigned int)f32_to_bf16(pre_activation(u2f(a1[u][2 * q]), d.pre_act, d.pre_slope)) |
-                        ((unsigned int)f32_to_bf16(pre_activation(u2f(a1[u][2 * q + 1]), d.pre_act, d.pre_slope)) << 16);
+            ap[q] = pack16<F16>(pre_activation(u2f(a0[u][2 * q]), d.pre_act, d.pre_slope), pre_activation(u2f(a0[u][2 * q + 1]), d.pre_act, d.pre_slope));
+            ap[2 + q] = pack16<F16>(pre_activation(u2f(a1[u][2 * q]), d.pre_act, d.pre_slope), pre_activation(u2f(a1[u][2 * q + 1]), d.pre_act, d.pre_slope));
           }
         }
         u32x4 bf[NH];
@@ -544,7 +541,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
         for (int h = 0; h < NH; ++h) bf[h] = b[h][u];  // copies: the slot is re-requested below while the MFMA may still read
 #pragma unroll
         for (int h = 0; h < NH; ++h)
-          acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, bf[h]), acc[h][0][0], 0, 0, 0);
+          acc[h][0][0] = mfma16<F16>(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, bf[h]), acc[h][0][0]);
         int nxt = base + u + DEPTH;
         nxt = nxt < n_steps ? nxt : n_steps - 1;  // the tail re-requests the last step (unused): no branch in the stream
         request(u, nxt);
@@ -655,7 +652,7 @@ static bool small_form_ok(int cout, int mode, int cols) {
   return mode != TTS_MODE_LINEAR || cout > 64;
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE>
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16 = false>
 static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   using C = ConvCfg<TM, TN, WAVES_M, WAVES_N, DUAL>;
   constexpr int BK = BF16 ? 64 : 32, ESZ = BF16 ? 2 : 4, NH = DUAL ? 2 : 1;
@@ -667,15 +664,14 @@ static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   const size_t xs_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7;
   const size_t lds = ((C::BM == 64 && !SNAKE ? 2 : 1) * xs_elems + (size_t)2 * NH * BK * C::BN) * ESZ;
   TTS_CHECK_ARG(lds <= 160 * 1024, "conv1d: LDS %zu B exceeds 160 KiB (taps %d dil %d)", lds, d.taps, d.dil);
-  auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE>;
-  static bool lds_raised = false;  // once per instantiation (also keeps the call out of stream captures)
-  if (lds > 64 * 1024 && !lds_raised) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE, F16>;
+  static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
+  if (lds > 64 * 1024) {
+    const hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(k), lds_raised);
     if (e != hipSuccess) {
       set_error("conv1d: raising the dynamic LDS limit failed: %s", hipGetErrorString(e));
       return TTS_E_LAUNCH;
     }
-    lds_raised = true;
   }
   hipLaunchKernelGGL(k, grid, block, lds, st, d);
   return launch_status("conv1d");
@@ -686,11 +682,13 @@ static int launch_cfg(const TtsConvDesc& d, hipStream_t st) {
   if constexpr (!DUAL) {
     if (d.pre_act == TTS_PRE_SNAKE) {  // only the (non-dual) vocoder convs carry the snake prologue
       if (d.compute == 0) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, false, true>(d, st);
+      if (d.compute == 2) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, true, true>(d, st);
       return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, true>(d, st);
     }
   }
   TTS_CHECK_ARG(d.pre_act != TTS_PRE_SNAKE, "conv1d: the snake prologue is not available in the dual modes");
   if (d.compute == 0) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, false, false>(d, st);
+  if (d.compute == 2) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, false, true>(d, st);
   return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, false>(d, st);
 }
 
@@ -717,17 +715,19 @@ static int launch_gemm_rows(const TtsConvDesc& d, hipStream_t st) {
   const bool dual = d.mode != TTS_MODE_LINEAR, xb = d.io_flags & TTS_IO_X_BF16;
   const int cols = dual ? d.half_pad : d.wn;
   dim3 grid(d.n_tiles, cols / 64), block(256);
-#define TTS_GEMM_ROWS(DUAL_, BF16_, XB_) hipLaunchKernelGGL((gemm_rows_kernel<DUAL_, BF16_, XB_>), grid, block, 0, st, d)
+#define TTS_GEMM_ROWS(DUAL_, BF16_, XB_, F16_) hipLaunchKernelGGL((gemm_rows_kernel<DUAL_, BF16_, XB_, F16_>), grid, block, 0, st, d)
+#define TTS_GEMM_ROWS2(DUAL_, XB_) do { if (d.compute == 2) TTS_GEMM_ROWS(DUAL_, true, XB_, true); else TTS_GEMM_ROWS(DUAL_, true, XB_, false); } while (0)
   if (d.compute == 0) {
-    if (dual) TTS_GEMM_ROWS(true, false, false);
-    else TTS_GEMM_ROWS(false, false, false);
+    if (dual) TTS_GEMM_ROWS(true, false, false, false);
+    else TTS_GEMM_ROWS(false, false, false, false);
   } else if (xb) {
-    if (dual) TTS_GEMM_ROWS(true, true, true);
-    else TTS_GEMM_ROWS(false, true, true);
+    if (dual) TTS_GEMM_ROWS2(true, true);
+    else TTS_GEMM_ROWS2(false, true);
   } else {
-    if (dual) TTS_GEMM_ROWS(true, true, false);
-    else TTS_GEMM_ROWS(false, true, false);
+    if (dual) TTS_GEMM_ROWS2(true, false);
+    else TTS_GEMM_ROWS2(false, false);
   }
+#undef TTS_GEMM_ROWS2
 #undef TTS_GEMM_ROWS
   return launch_status("conv1d (1-tap rows)");
 }
@@ -737,6 +737,9 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.cin > 0 && d.cout > 0 && d.taps > 0 && d.dil > 0, "conv1d: bad dims");
   TTS_CHECK_ARG(d.cin_pad % 32 == 0 && d.cin_pad >= d.cin, "conv1d: cin_pad %d must be a multiple of 32 >= cin %d", d.cin_pad, d.cin);
   TTS_CHECK_ARG(d.mode >= 0 && d.mode <= 3, "conv1d: bad mode %d", d.mode);
+  TTS_CHECK_ARG(d.compute >= 0 && d.compute <= 2, "conv1d: bad compute %d (0 fp32, 1 bf16, 2 fp16)", d.compute);
+  TTS_CHECK_ARG(d.compute == 0 || ((d.io_flags & TTS_IO_F16) != 0) == (d.compute == 2) || !(d.io_flags & 7),
+                "conv1d: the 16-bit tensors of a bf16 / fp16 call must be in the call's own format");
   TTS_CHECK_ARG(d.mode != TTS_MODE_COUPLING || d.aux, "conv1d: coupling mode needs aux");
   TTS_CHECK_ARG(d.pre_act != TTS_PRE_SNAKE || (d.snake_alpha && d.snake_beta && d.snake_filt), "conv1d: PRE_SNAKE needs alpha/beta/filter");
   if (d.n_tiles == 0) return TTS_OK;

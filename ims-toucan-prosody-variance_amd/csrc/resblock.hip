@@ -22,8 +22,6 @@
 
 namespace tts {
 
-__device__ __forceinline__ unsigned short rb_f2bf(float f) { return f32_to_bf16(f); }
-__device__ __forceinline__ float rb_bf2f(unsigned short u) { return bf16_to_f32(u); }
 
 #ifndef RB_C32_WAVES
 #define RB_C32_WAVES 4      // waves per SIMD the C = 32 instantiation is compiled for (tuning knob, see the launch bounds)
@@ -97,7 +95,8 @@ struct RbSlab {
 
 // waves per SIMD the register allocation must leave room for: 2 / 2 / 1 / 1 workgroups per CU (C = 32 / 64 / 128 / 256)
 // IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
-template <int C, bool IOB>
+// F16: the 16-bit element format everywhere in the kernel (LDS tiles, weights, 16-bit x / y) is IEEE fp16 instead of bf16
+template <int C, bool IOB, bool F16>
 // (C = 32: with the prefetching snake two spill-free workgroups per CU beat three at the 80-register cap by ~10 %)
 __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d) {
   constexpr int RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
@@ -188,12 +187,12 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
           const float ea = expf(d.alpha1[cg]), ib = 1.0f / (expf(d.beta1[cg]) + 1e-9f);
           auto st = [&](int i, float v) {
             if constexpr (RbCfg<C>::UNGUARDED)
-              xa[(wr0 + i) * XP + chl] = rb_f2bf((unsigned)(t0 + i) < (unsigned)T ? v : 0.0f);
+              xa[(wr0 + i) * XP + chl] = to16<F16>((unsigned)(t0 + i) < (unsigned)T ? v : 0.0f);
             else if (wr0 + i < win_rows)
-              xa[(wr0 + i) * XP + chl] = rb_f2bf((t0 + i >= 0 && t0 + i < T) ? v : 0.0f);
+              xa[(wr0 + i) * XP + chl] = to16<F16>((t0 + i >= 0 && t0 + i < T) ? v : 0.0f);
           };
           if constexpr (IOB)
-            snake_stream<NCH1, C != 32 || RB_C32_PREFETCH>([&](int q) { return rb_bf2f(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, st, T, t0, f, ea, ib);
+            snake_stream<NCH1, C != 32 || RB_C32_PREFETCH>([&](int q) { return from16<F16>(xh[(size_t)(tile.seq_begin + q) * d.ldx + cg]); }, st, T, t0, f, ea, ib);
           else
             snake_stream<NCH1, C != 32 || RB_C32_PREFETCH>([&](int q) { return d.x[(size_t)(tile.seq_begin + q) * d.ldx + cg]; }, st, T, t0, f, ea, ib);
         } else {
@@ -225,10 +224,10 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
           unsigned int o4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float lo = rb_bf2f(w4[q] & 0xFFFF), hi2 = rb_bf2f(w4[q] >> 16);
+            float lo = from16<F16>(w4[q] & 0xFFFF), hi2 = from16<F16>(w4[q] >> 16);
             lo = lo > 0.f ? lo : lo * d.slope;
             hi2 = hi2 > 0.f ? hi2 : hi2 * d.slope;
-            o4[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
+            o4[q] = pack16<F16>(lo, hi2);
           }
           *reinterpret_cast<uint4*>(xa + wr * XP + c8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
         }
@@ -254,12 +253,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
           int e = base + p * RB_THREADS;
           e = e < total ? e : total - 1;
           const int wr = e / Q4, c4 = (e % Q4) * 4;
-          ushort4 o;
-          o.x = rb_f2bf(v[p].x > 0.f ? v[p].x : v[p].x * d.slope);
-          o.y = rb_f2bf(v[p].y > 0.f ? v[p].y : v[p].y * d.slope);
-          o.z = rb_f2bf(v[p].z > 0.f ? v[p].z : v[p].z * d.slope);
-          o.w = rb_f2bf(v[p].w > 0.f ? v[p].w : v[p].w * d.slope);
-          *reinterpret_cast<ushort4*>(xa + wr * XP + c4) = o;
+          *reinterpret_cast<uint2*>(xa + wr * XP + c4) =
+              make_uint2(pack16<F16>(v[p].x > 0.f ? v[p].x : v[p].x * d.slope, v[p].y > 0.f ? v[p].y : v[p].y * d.slope),
+                         pack16<F16>(v[p].z > 0.f ? v[p].z : v[p].z * d.slope, v[p].w > 0.f ? v[p].w : v[p].w * d.slope));
         }
       }
     }
@@ -276,7 +272,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            acc[j] = mfma16<F16>(a, b, acc[j]);
           }
         }
       }
@@ -298,7 +294,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       float v = acc[j][r] + b1;
       if (!snake) v = v > 0.f ? v : v * d.slope;
       if (t < 0 || t >= T) v = 0.0f;  // act2 output outside the utterance is conv2's zero padding
-      t1[i * TP + n] = rb_f2bf(v);
+      t1[i * TP + n] = to16<F16>(v);
       acc[j][r] = 0.0f;
     }
   }
@@ -314,8 +310,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         snake_stream<RB_M1 / 8>([&](int q2) {
           int i = q2 - base;
           i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);
-          return rb_bf2f(t1[i * TP + chn]);
-        }, [&](int i, float v) { t1[i * TP + chn] = rb_f2bf((t0 + i >= 0 && t0 + i < T) ? v : 0.0f); }, T, t0, f, expf(d.alpha2[chn]),
+          return from16<F16>(t1[i * TP + chn]);
+        }, [&](int i, float v) { t1[i * TP + chn] = to16<F16>((t0 + i >= 0 && t0 + i < T) ? v : 0.0f); }, T, t0, f, expf(d.alpha2[chn]),
                                 1.0f / (expf(d.beta2[chn]) + 1e-9f));
       } else {
         for (int i = 0; i < RB_M1; ++i) t1[i * TP + chn] = 0;
@@ -340,7 +336,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
           snake_stream<NCH2, C != 32 || RB_C32_PREFETCH>([&](int q2) {
             int i = q2 - base;
             i = i < 0 ? 0 : (i > RB_M1 - 1 ? RB_M1 - 1 : i);  // only reached by rows whose outputs are not consumed
-            return rb_bf2f(t1[i * TP + chn]);
+            return from16<F16>(t1[i * TP + chn]);
           }, [&](int i, float v) { o[q][i] = (RbCfg<C>::UNGUARDED ? (unsigned)(t0 + i) < (unsigned)T : (t0 + i >= 0 && t0 + i < T)) ? v : 0.0f; }, T, t0, f, expf(d.alpha2[chn]),
                              1.0f / (expf(d.beta2[chn]) + 1e-9f));
         }
@@ -351,7 +347,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         const int it = tid + q * RB_THREADS;
         const int chn = it % C, i0 = (it / C) * GR;
 #pragma unroll
-        for (int i = 0; i < GR; ++i) t1[(i0 + i) * TP + chn] = rb_f2bf(o[q][i]);
+        for (int i = 0; i < GR; ++i) t1[(i0 + i) * TP + chn] = to16<F16>(o[q][i]);
       }
     }
   }
@@ -373,7 +369,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
               const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+              acc[j] = mfma16<F16>(a, b, acc[j]);
             }
           }
         }
@@ -413,9 +409,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       unsigned int o4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float lo = ov[2 * q] + d.res_scale * rb_bf2f(xw[q] & 0xFFFF), hi2 = ov[2 * q + 1] + d.res_scale * rb_bf2f(xw[q] >> 16);
-        if (d.accumulate) { lo += rb_bf2f(yw[q] & 0xFFFF); hi2 += rb_bf2f(yw[q] >> 16); }
-        o4[q] = (unsigned int)rb_f2bf(lo) | ((unsigned int)rb_f2bf(hi2) << 16);
+        float lo = ov[2 * q] + d.res_scale * from16<F16>(xw[q] & 0xFFFF), hi2 = ov[2 * q + 1] + d.res_scale * from16<F16>(xw[q] >> 16);
+        if (d.accumulate) { lo += from16<F16>(yw[q] & 0xFFFF); hi2 += from16<F16>(yw[q] >> 16); }
+        o4[q] = pack16<F16>(lo, hi2);
       }
       *reinterpret_cast<uint4*>(yh + (size_t)row * d.ldy + c8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
     }
@@ -442,7 +438,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #undef load_slab
 #undef store_slab
 
-template <int C, bool IOB>
+template <int C, bool IOB, bool F16>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   constexpr int KC = RbCfg<C>::KC, RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   const int h1 = (d.taps - 1) / 2 * d.dil;
@@ -451,11 +447,11 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2;
   if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
-  auto k = resblock_step_kernel<C, IOB>;
-  static bool lds_raised = false;  // once per instantiation (also keeps the call out of stream captures)
-  if (lds > 64 * 1024 && !lds_raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    lds_raised = true;
+  auto k = resblock_step_kernel<C, IOB, F16>;
+  static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
+  if (lds > 64 * 1024 && raise_lds_limit(reinterpret_cast<const void*>(k), lds_raised) != hipSuccess) {
+    set_error("resblock_step: raising the dynamic LDS limit failed");
+    return TTS_E_LAUNCH;
   }
   hipLaunchKernelGGL(k, dim3(d.n_tiles), dim3(RB_THREADS), lds, st, d);
   return launch_status("resblock_step");
@@ -474,21 +470,22 @@ int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.act != TTS_PRE_SNAKE || (d.alpha1 && d.beta1 && d.alpha2 && d.beta2 && d.filt), "resblock_step: snake parameters missing");
   TTS_CHECK_ARG((d.ldx & 3) == 0 && ((uintptr_t)d.x & 15) == 0, "resblock_step: x must be 16-byte aligned rows");
   TTS_CHECK_ARG(!d.io_bf16 || ((d.ldx & 7) == 0 && (d.ldy & 7) == 0 && ((uintptr_t)d.y & 15) == 0), "resblock_step: bf16 rows must be 16-byte aligned");
+  TTS_CHECK_ARG(d.compute == 1 || d.compute == 2, "resblock_step: compute must be 1 (bf16) or 2 (fp16), got %d", d.compute);
   if (d.n_tiles == 0) return TTS_OK;
-  if (d.io_bf16) {
-    switch (d.c) {
-      case 32: return launch_rb<32, true>(d, st);
-      case 64: return launch_rb<64, true>(d, st);
-      case 128: return launch_rb<128, true>(d, st);
-      default: return launch_rb<256, true>(d, st);
-    }
+#define TTS_RB(IOB_, F16_)                                    \
+  switch (d.c) {                                              \
+    case 32: return launch_rb<32, IOB_, F16_>(d, st);         \
+    case 64: return launch_rb<64, IOB_, F16_>(d, st);         \
+    case 128: return launch_rb<128, IOB_, F16_>(d, st);       \
+    default: return launch_rb<256, IOB_, F16_>(d, st);        \
   }
-  switch (d.c) {
-    case 32: return launch_rb<32, false>(d, st);
-    case 64: return launch_rb<64, false>(d, st);
-    case 128: return launch_rb<128, false>(d, st);
-    default: return launch_rb<256, false>(d, st);
+  if (d.compute == 2) {
+    if (d.io_bf16) { TTS_RB(true, true) }
+    TTS_RB(false, true)
   }
+  if (d.io_bf16) { TTS_RB(true, false) }
+  TTS_RB(false, false)
+#undef TTS_RB
 }
 
 }  // namespace tts

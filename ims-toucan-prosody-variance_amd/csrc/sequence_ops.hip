@@ -269,7 +269,7 @@ template <int NCH, bool XB, bool YB>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
                                                        const float* __restrict__ filt, int c, const TtsTile* __restrict__ tiles,
-                                                       int tile_rows) {
+                                                       int tile_rows, int f16) {
   const TtsTile t = tiles[blockIdx.x];
   // work item = (8*NCH frames, channel), streamed (snake.h) so that only the first 8 frames pay the filter halo; consecutive
   // threads take consecutive channels, so a wavefront touches one contiguous run per row.  The 2x-rate signal lives in registers.
@@ -288,10 +288,10 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
   const float inv_b = 1.0f / (expf(beta[ch]) + 1e-9f);
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(x);
   unsigned short* __restrict__ yh = reinterpret_cast<unsigned short*>(y);
-  snake_stream<NCH>([&](int q) { return XB ? bf16_to_f32(xh[(size_t)(t.seq_begin + q) * ldx + ch]) : x[(size_t)(t.seq_begin + q) * ldx + ch]; },
+  snake_stream<NCH>([&](int q) { return XB ? load16(xh[(size_t)(t.seq_begin + q) * ldx + ch], f16) : x[(size_t)(t.seq_begin + q) * ldx + ch]; },
                     [&](int i, float v) {
                       if (r0 + i < r_end) {
-                        if (YB) yh[(size_t)(r0 + i) * ldy + ch] = f32_to_bf16(v);
+                        if (YB) yh[(size_t)(r0 + i) * ldy + ch] = store16(v, f16);
                         else y[(size_t)(r0 + i) * ldy + ch] = v;
                       }
                     }, t.seq_end - t.seq_begin, r0 - t.seq_begin, f, ea, inv_b);
@@ -306,7 +306,7 @@ int snake_aa(const float* x, int ldx, float* y, int ldy, const float* alpha, con
   dim3 grid(n_tiles, (items + 255) / 256), block(256);
   const bool xb = io_flags & TTS_IO_X_BF16, yb = io_flags & TTS_IO_Y_BF16;
 #define TTS_SNAKE_LAUNCH(XB, YB) \
-  hipLaunchKernelGGL((snake_aa_kernel<NCH, XB, YB>), grid, block, 0, st, x, ldx, y, ldy, alpha, beta, filt, c, tiles, tile_rows)
+  hipLaunchKernelGGL((snake_aa_kernel<NCH, XB, YB>), grid, block, 0, st, x, ldx, y, ldy, alpha, beta, filt, c, tiles, tile_rows, (io_flags & TTS_IO_F16) ? 1 : 0)
   if (xb && yb) TTS_SNAKE_LAUNCH(true, true);
   else if (xb) TTS_SNAKE_LAUNCH(true, false);
   else if (yb) TTS_SNAKE_LAUNCH(false, true);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict_
     const int r = t.row0 - 3 + wr;
     float v = 0.f;
     if (r >= t.seq_begin && r < t.seq_end)
-      v = (io_flags & TTS_IO_X_BF16) ? bf16_to_f32(reinterpret_cast<const unsigned short*>(x)[(size_t)r * ldx + ch]) : x[(size_t)r * ldx + ch];
+      v = (io_flags & TTS_IO_X_BF16) ? load16(reinterpret_cast<const unsigned short*>(x)[(size_t)r * ldx + ch], io_flags & TTS_IO_F16) : x[(size_t)r * ldx + ch];
     if (pre_act == TTS_PRE_LRELU) v = v > 0.f ? v : v * pre_slope;
     xs[wr * pitch + ch] = v;
   }
@@ -372,7 +372,7 @@ template <bool XB>
 __global__ __launch_bounds__(256) void conv_post_snake_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, float bias,
                                                              const float* __restrict__ alpha, const float* __restrict__ beta,
                                                              const float* __restrict__ filt, float* __restrict__ wav,
-                                                             const TtsTile* __restrict__ tiles) {
+                                                             const TtsTile* __restrict__ tiles, int f16) {
   __shared__ float xs[CPS_WIN * (CPS_C + 1)];
   __shared__ float wsm[7 * CPS_C];
   const TtsTile t = tiles[blockIdx.x];
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void conv_post_snake_kernel(const float* __res
   if (t0 + 31 >= 0 && t0 < T) {
     const float ea = expf(alpha[ch]), ib = 1.0f / (expf(beta[ch]) + 1e-9f);
     const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(x);
-    snake_stream<4>([&](int q) { return XB ? bf16_to_f32(xh[(size_t)(t.seq_begin + q) * ldx + ch]) : x[(size_t)(t.seq_begin + q) * ldx + ch]; },
+    snake_stream<4>([&](int q) { return XB ? load16(xh[(size_t)(t.seq_begin + q) * ldx + ch], f16) : x[(size_t)(t.seq_begin + q) * ldx + ch]; },
                     [&](int i, float v) { col[i * (CPS_C + 1)] = (t0 + i >= 0 && t0 + i < T) ? v : 0.0f; }, T, t0, f, ea, ib);
   } else {
 #pragma unroll
@@ -417,9 +417,9 @@ int conv_post_snake(const float* x, int ldx, int cin, const float* w, float bias
   TTS_CHECK_ARG(tile_rows == CPS_TILE, "conv_post_snake: tile table must use %d rows, got %d", CPS_TILE, tile_rows);
   if (n_tiles == 0) return TTS_OK;
   if (io_flags & TTS_IO_X_BF16)
-    hipLaunchKernelGGL(conv_post_snake_kernel<true>, dim3(n_tiles), dim3(256), 0, st, x, ldx, w, bias, alpha, beta, filt, wav, tiles);
+    hipLaunchKernelGGL(conv_post_snake_kernel<true>, dim3(n_tiles), dim3(256), 0, st, x, ldx, w, bias, alpha, beta, filt, wav, tiles, (io_flags & TTS_IO_F16) ? 1 : 0);
   else
-    hipLaunchKernelGGL(conv_post_snake_kernel<false>, dim3(n_tiles), dim3(256), 0, st, x, ldx, w, bias, alpha, beta, filt, wav, tiles);
+    hipLaunchKernelGGL(conv_post_snake_kernel<false>, dim3(n_tiles), dim3(256), 0, st, x, ldx, w, bias, alpha, beta, filt, wav, tiles, 0);
   return launch_status("conv_post_snake");
 }
 

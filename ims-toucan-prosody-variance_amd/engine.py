@@ -15,8 +15,8 @@ import numpy as np
 import torch
 
 from . import capi, packing
-from .capi import (ACT_NONE, ACT_RELU, ACT_TANH, COMPUTE_BF16, COMPUTE_F32, MODE_COUPLING, MODE_GATED, MODE_GLU, MODE_LINEAR,
-                   PRE_LRELU, PRE_NONE, PRE_SNAKE)
+from .capi import (ACT_NONE, ACT_RELU, ACT_TANH, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, MODE_COUPLING, MODE_GATED, MODE_GLU,
+                   MODE_LINEAR, PRE_LRELU, PRE_NONE, PRE_SNAKE)
 from .ragged import Ragged
 
 ATT, HEADS, DK = 192, 4, 48
@@ -27,7 +27,24 @@ def _ptr(t):
 
 
 def _is_bf16(t):
-    return t is not None and t.dtype == torch.bfloat16
+    """t is a 16-bit tensor in HBM (bf16 in the bf16 configuration, fp16 in the fp16 one)."""
+    return t is not None and t.dtype in (torch.bfloat16, torch.float16)
+
+
+def _f16_flag(*ts):
+    return capi.IO_F16 if any(t is not None and t.dtype == torch.float16 for t in ts) else 0
+
+
+def precision_of(bf16, precision):
+    """(`bf16` flag of the older API, `precision` in {None, "f32", "bf16", "f16"}) -> (name, pack argument, compute, torch dtype)."""
+    name = precision if precision is not None else ("bf16" if bf16 else "f32")
+    if name in ("fp32", "f32"):
+        return "f32", False, COMPUTE_F32, torch.float32
+    if name == "bf16":
+        return "bf16", "bf16", COMPUTE_BF16, torch.bfloat16
+    if name in ("fp16", "f16"):
+        return "f16", "f16", COMPUTE_F16, torch.float16
+    raise ValueError(f"precision {name!r}: expected f32, bf16 or f16")
 
 
 def _ld(t):
@@ -42,12 +59,19 @@ def _ld(t):
 class Ops:
     """Thin typed wrappers over the C ABI; all launches go to the current torch stream of `device`."""
 
-    def __init__(self, device):
-        self.lib = capi.lib()
+    def __init__(self, device, lib=None):
+        """lib: the loaded libtoucan_hip.so (default) - or, in tests only, the numpy ABI emulator working on host memory."""
+        self.lib = capi.lib() if lib is None else lib
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if isinstance(self.lib, C.CDLL) and self.device.type != "cuda":
+            # the kernels dereference device pointers: host tensors would end in a GPU memory fault, not in a Python error
+            raise capi.ToucanHipError(f"device {str(self.device)!r}: libtoucan_hip.so has no CPU path - construct the engines / the "
+                                      f"interface with device='cuda' (the reference's default 'cpu' cannot be served)")
         self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
         self.small_tile_blocks = int(os.environ.get("TOUCAN_SMALL_TILE_BLOCKS", "1536"))  # regular conv grids below this many workgroups switch to the 64 x 64 small-batch form (0: never)
-        self.default_compute = COMPUTE_F32  # convs whose weights carry a bf16 copy run on bf16 MFMA when this is COMPUTE_BF16
+        self.default_compute = COMPUTE_F32  # convs whose weights carry a 16-bit copy run on bf16 / fp16 MFMA when this is not COMPUTE_F32
 
     def stream(self):
         if self.device.type == "cuda":
@@ -70,8 +94,8 @@ class Ops:
         tiles, n_tiles = rag.tiles(tile_rows)
         d = capi.TtsConvDesc()
         d.x, d.ldx, d.cin = x.data_ptr(), _ld(x), cw.cin
-        use_bf16 = compute == COMPUTE_BF16 and cw.w_bf16 is not None
-        d.w = cw.w_bf16.data_ptr() if use_bf16 else cw.w.data_ptr()
+        use_bf16 = compute != COMPUTE_F32 and cw.w16 is not None  # the conv then runs in the format of its own 16-bit copy
+        d.w = cw.w16.data_ptr() if use_bf16 else cw.w.data_ptr()
         d.cin_pad, d.wn, d.half_pad = cw.cin_pad, cw.wn, cw.half_pad
         d.bias = _ptr(cw.bias)
         d.y, d.ldy, d.cout = y.data_ptr(), _ld(y), cw.cout
@@ -85,9 +109,10 @@ class Ops:
         d.res, d.ld_res, d.res_scale = _ptr(res), _ld(res), res_scale
         d.aux, d.ld_aux = _ptr(aux), _ld(aux)
         d.accumulate = 1 if accumulate else 0
-        d.compute = COMPUTE_BF16 if use_bf16 else COMPUTE_F32
-        # bf16 tensors in HBM are recognised by dtype (strides are already in elements)
-        d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0)
+        d.compute = cw.compute16 if use_bf16 else COMPUTE_F32
+        # 16-bit tensors in HBM are recognised by dtype (strides are already in elements)
+        d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0) \
+            | _f16_flag(x, y, res)
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
         if tm is not None and tm.wants(cw, d.compute, tile_rows):
@@ -95,7 +120,7 @@ class Ops:
             ev0.record()
             capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
             ev1.record()
-            tm.add(cw, d.compute, sum(rag.lengths), ev0, ev1, tile_rows)
+            tm.add(cw, d.compute, sum(rag.lengths), ev0, ev1, tile_rows, x.element_size(), y.element_size())
         else:
             capi.check(self.lib.tts_conv1d(C.byref(d), self.stream()), "tts_conv1d")
         return y
@@ -108,14 +133,16 @@ class Ops:
         d = capi.TtsResblockDesc()
         d.x, d.ldx, d.y, d.ldy = x.data_ptr(), _ld(x), y.data_ptr(), _ld(y)
         d.c, d.taps, d.dil = c1.cin, c1.taps, c1.dil
-        d.w1, d.b1, d.w2, d.b2 = c1.w_bf16.data_ptr(), c1.bias.data_ptr(), c2.w_bf16.data_ptr(), c2.bias.data_ptr()
+        d.w1, d.b1, d.w2, d.b2 = c1.w16.data_ptr(), c1.bias.data_ptr(), c2.w16.data_ptr(), c2.bias.data_ptr()
+        assert c1.compute16 == c2.compute16 != COMPUTE_F32
+        d.compute = c1.compute16
         d.act, d.slope = act, slope
         if snake1 is not None:
             d.alpha1, d.beta1 = snake1[0].data_ptr(), snake1[1].data_ptr()
             d.alpha2, d.beta2 = snake2[0].data_ptr(), snake2[1].data_ptr()
             d.filt = filt.data_ptr()
         d.alpha, d.res_scale, d.accumulate = alpha, res_scale, 1 if accumulate else 0
-        assert _is_bf16(x) == _is_bf16(y)
+        assert x.dtype == y.dtype and (not _is_bf16(x) or (x.dtype == torch.float16) == (c1.compute16 == COMPUTE_F16))
         d.io_bf16 = 1 if _is_bf16(x) else 0
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
@@ -125,7 +152,9 @@ class Ops:
             capi.check(self.lib.tts_resblock_step(C.byref(d), self.stream()), "tts_resblock_step")
             ev1.record()
             rows = sum(rag.lengths)
-            tm.add_named("resblock_step<%d>" % c1.cin, 2.0 * rows * c1.cin * c1.cin * c1.taps * 2, ev0, ev1)
+            # algorithmic bytes: x read once + y written once (in their HBM element size) + both weight sets once
+            nbytes = 2.0 * rows * c1.cin * x.element_size() + 2.0 * c1.taps * c1.cin * c1.cin * 2
+            tm.add_named("resblock_step<%d>" % c1.cin, 2.0 * rows * c1.cin * c1.cin * c1.taps * 2, ev0, ev1, nbytes, float(rows) * c1.cin)
         else:
             capi.check(self.lib.tts_resblock_step(C.byref(d), self.stream()), "tts_resblock_step")
         return y
@@ -197,7 +226,7 @@ class Ops:
 
     def snake_aa(self, x, y, alpha, beta, filt, c, rag):
         tiles, n = rag.tiles(256)  # 8 streamed groups of 32 frames per tile: 256 work items already at c = 32
-        flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0)
+        flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | _f16_flag(x, y)
         capi.check(self.lib.tts_snake_aa(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), alpha.data_ptr(), beta.data_ptr(), filt.data_ptr(), c,
                                          tiles.data_ptr(), n, 256, flags, self.stream()), "tts_snake_aa")
         return y
@@ -205,14 +234,14 @@ class Ops:
     def conv_post(self, x, cin, w, bias, pre, slope, wav, rag):
         tiles, n = rag.tiles(256)
         capi.check(self.lib.tts_conv_post(x.data_ptr(), _ld(x), cin, w.data_ptr(), bias, pre, slope, wav.data_ptr(), tiles.data_ptr(), n,
-                                          256, capi.IO_X_BF16 if _is_bf16(x) else 0, self.stream()), "tts_conv_post")
+                                          256, (capi.IO_X_BF16 if _is_bf16(x) else 0) | _f16_flag(x), self.stream()), "tts_conv_post")
         return wav
 
     def conv_post_snake(self, x, cin, w, bias, alpha, beta, filt, wav, rag):
         tr = self.lib.tts_conv_post_snake_tile_rows()
         tiles, n = rag.tiles(tr)
         capi.check(self.lib.tts_conv_post_snake(x.data_ptr(), _ld(x), cin, w.data_ptr(), bias, alpha.data_ptr(), beta.data_ptr(), filt.data_ptr(),
-                                                wav.data_ptr(), tiles.data_ptr(), n, tr, capi.IO_X_BF16 if _is_bf16(x) else 0, self.stream()),
+                                                wav.data_ptr(), tiles.data_ptr(), n, tr, (capi.IO_X_BF16 if _is_bf16(x) else 0) | _f16_flag(x), self.stream()),
                    "tts_conv_post_snake")
         return wav
 
@@ -251,10 +280,12 @@ class GraphCache:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = fn(**static)
-            entry = self.entries[key] = (graph, static, outs)
+            # `fn` stays referenced by the entry: its closure owns every external device buffer the captured launches read by raw
+            # pointer (the Ragged layouts with their tile tables and bounds) - they must outlive Ragged's own layout cache
+            entry = self.entries[key] = (graph, static, outs, fn)
             graph.replay()
             return outs
-        graph, static, outs = entry
+        graph, static, outs, _keep = entry
         for k, v in inputs.items():
             if v is not None:
                 static[k].copy_(v)
@@ -303,16 +334,19 @@ class ConformerWeights:
 class AcousticEngine:
     """InferenceToucanTTS.ToucanTTS (:16-319) for a ragged batch of utterances."""
 
-    def __init__(self, state_dict, device, bf16=False, use_graphs=False):
-        """bf16=True: Conformer / PostNet / PostFlow GEMMs on bf16 MFMA with fp32 accumulation and fp32 activations
-        (BASELINE.json configs[2]); the variance predictors, all norms, softmax and the flow state stay fp32."""
+    def __init__(self, state_dict, device, bf16=False, use_graphs=False, precision=None):
+        """precision "bf16" (or bf16=True): Conformer / PostNet / PostFlow GEMMs on bf16 MFMA with fp32 accumulation and fp32
+        activations (BASELINE.json configs[2]); "f16": the same GEMMs on fp16 MFMA (configs[4]).  In both, the variance predictors,
+        all norms, softmax, the coupling output conv and the flow state stay fp32 (fp16 exp(-logs) chains
+        over 18 blocks overflow otherwise)."""
         self.ops = Ops(device)
         self.device = self.ops.device
-        self.bf16 = bf16
+        self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
+        self.bf16 = bool(bf16)  # a 16-bit MFMA configuration (either format)
         self.use_graphs = use_graphs
         self._graphs = GraphCache(self.device)
         if bf16:
-            self.ops.default_compute = COMPUTE_BF16
+            self.ops.default_compute = compute16
         dev = self.device
         sd = packing.fold_weight_norm(state_dict)
         self.multilingual = "encoder.language_embedding.weight" in sd
@@ -394,6 +428,8 @@ class AcousticEngine:
         """ptab_l[pmax-1+p] = linear_pos_l(pe(p)) for every block l (Attention.py:177, PositionalEncoding.py:90-130)."""
         if cw.pmax >= pmax:
             return
+        # captured graphs hold the old tables' addresses and the old pmax: drop them before the tables are released
+        self._graphs.entries.clear()
         pmax = max(pmax, 2 * cw.pmax, 256)
         ops = self.ops
         pe = _dev(packing.rel_pos_encoding(pmax), self.device)
@@ -410,7 +446,7 @@ class AcousticEngine:
         ln = ops.empty(R, ATT)
         # tensors consumed only by bf16-MFMA convs are kept as bf16 in HBM: the consumer would round them to bf16 while staging
         # anyway (same round-to-nearest-even), so the result is bit-identical and the round trip costs half the bytes
-        hid = ops.empty(R, 1536, dtype=torch.bfloat16 if self.bf16 else torch.float32)
+        hid = ops.empty(R, 1536, dtype=self.dt16)
         qkv = ops.empty(R, 3 * ATT)
         ctx = ops.empty(R, ATT)
         glu = ops.empty(R, ATT)
@@ -541,6 +577,10 @@ class AcousticEngine:
         With ``use_graphs`` (CUDA devices, no taps) the two shape-static halves of the pass are captured once per shape
         signature into HIP graphs and replayed: ~900 launches become two graph launches, which is what batch-1 latency
         needs.  Tensors in the returned dict are then views of graph-owned buffers, valid until the next call."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):  # launches go to streams of self.device: it must be the current HIP device
+                return self.forward(texts, utt_embs, lang_ids, durations, pitch, energy, z_noise, duration_scaling_factor,
+                                    pitch_variance_scale, energy_variance_scale, pause_duration_scaling_factor, run_postflow, taps, generator)
         ops, dev = self.ops, self.device
         B = len(texts)
         assert duration_scaling_factor > 0
@@ -617,7 +657,7 @@ class AcousticEngine:
         x.copy_(z_sq)
         hs = ops.empty(RS, 2 * ATT)  # [hidden state | skip sum] side by side: one accumulating conv per WaveNet layer updates both
         h, skip = hs[:, :ATT], hs[:, ATT:]
-        acts = ops.empty(RS, ATT, dtype=torch.bfloat16 if self.bf16 else torch.float32)  # read only by the res/skip conv (bf16 MFMA)
+        acts = ops.empty(RS, ATT, dtype=self.dt16)  # read only by the res/skip conv (16-bit MFMA)
         cond = ops.empty(RS, 8 * ATT)
         for b in reversed(range(18)):
             blk = self.flow[b]
@@ -641,8 +681,10 @@ class VocoderEngine:
     KS = (3, 7, 11)
     DIL = (1, 3, 5)
 
-    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False, fuse_step=None, store_bf16=None, use_graphs=False):
+    def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False, fuse_step=None, store_bf16=None, use_graphs=False,
+                 precision=None):
         assert kind in ("bigvgan", "hifigan")
+        self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
         self.kind = kind
         self.use_graphs = use_graphs
         self._graphs = GraphCache(device)
@@ -650,15 +692,15 @@ class VocoderEngine:
         # its own kernel.  Measured on MI355X (batch 32, bf16): 122.5 ms/step fused vs 119.0 ms/step unfused - the fused
         # variant needs 111-131 VGPRs and loses occupancy, so the stand-alone kernel is the default for now.
         self.fuse_snake = fuse_snake
-        # bf16 only: one fused kernel per residual dilation step (tts_resblock_step) for the stages with C <= 128
-        self.fuse_step = bf16 if fuse_step is None else (fuse_step and bf16)
+        # 16-bit modes only: one fused kernel per residual dilation step (tts_resblock_step) for the stages with C <= 128
+        self.fuse_step = bool(bf16) if fuse_step is None else bool(fuse_step and bf16)
         # C = 256 (stage 1) is supported by the fused kernel too, but with one 4-wave workgroup per CU it only ties the
         # unfused convs + stand-alone snakes (9.1 vs 9.0 ms per step measured), so stage 1 keeps the unfused path
         self.fuse_max_channels = 128
         self.store_bf16 = self.fuse_step if store_bf16 is None else (store_bf16 and self.fuse_step)
         self.ops = Ops(device)
         self.device = self.ops.device
-        self.compute = COMPUTE_BF16 if bf16 else COMPUTE_F32
+        self.compute = compute16
         dev = self.device
         sd = packing.fold_weight_norm(state_dict)
         if kind == "bigvgan":
@@ -695,6 +737,9 @@ class VocoderEngine:
     @torch.inference_mode()
     def forward(self, mel_packed, rag, taps=None):
         """mel_packed [rows,80] time-major (utterance u at rag.begins[u], rag.lengths[u] frames) -> (wav packed, Ragged)."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index:
+            with torch.cuda.device(self.device):
+                return self.forward(mel_packed, rag, taps)
         if self.use_graphs and taps is None and self.device.type == "cuda":
             key = (tuple(rag.lengths), tuple(rag.begins), int(mel_packed.shape[0]))
             wav = self._graphs.run(key, dict(mel_packed=mel_packed.contiguous()), lambda mel_packed: self._forward(mel_packed, rag, None)[0])
@@ -712,7 +757,7 @@ class VocoderEngine:
             # transposed conv as a 3-tap polyphase conv; [R, u*ch] re-viewed as [R*u, ch]
             # stages that run the fused residual step keep their residual stream as bf16 in HBM (bandwidth-bound kernels)
             fused = self.fuse_step and ch <= self.fuse_max_channels
-            sdt = torch.bfloat16 if self.store_bf16 else torch.float32  # (the unfused C = 256 stage included: its convs and snakes take bf16 I/O)
+            sdt = self.dt16 if self.store_bf16 else torch.float32  # (the unfused C = 256 stage included: its convs and snakes take 16-bit I/O)
             y = ops.conv(self.ups[i], x, ops.empty(R, u * ch, dtype=sdt), rag, pre=PRE_NONE if big else PRE_LRELU, pre_slope=0.1, compute=cp)
             R, rag = R * u, rag.scaled(u)
             xs = y.view(R, ch)

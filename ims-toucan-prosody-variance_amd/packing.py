@@ -8,7 +8,7 @@ InferenceAvocodo.py:82-89) and ``InvConvNear.store_inverse`` (Glow.py:130-139):
 * BatchNorm(eval) of the Conformer conv module folded into the depthwise conv (Convolution.py:26-27)
 * the 18 LU-parametrised 4x4 flow matrices inverted (fp64 on the host, stored fp32)
 * Conv1d / Linear weights re-laid as [tap][cin_pad][cout_pad] (the B operand of the implicit GEMM),
-  optionally also as bf16 [tap][cin_pad/8][cout_pad][8]
+  optionally also as bf16 or fp16 [tap][cin_pad/8][cout_pad][8]
 * ConvTranspose1d (k = 2*stride, padding = stride/2) rewritten as a 3-tap polyphase conv whose output
   row holds the `stride` output samples of one input frame
 * q/k/v projections concatenated into one [192 -> 576] GEMM; GLU / gated / coupling convs split in halves
@@ -85,11 +85,16 @@ class ConvWeights:
         else:
             packed[:, :cin, : self.cout] = w_kio
         self.w = torch.from_numpy(packed).to(device)
-        self.w_bf16 = None
+        # optional 16-bit copy for the bf16 / fp16 MFMA paths: `bf16` is False, True / "bf16", or "f16" (one format per conv)
+        self.w16 = None
+        self.compute16 = capi.COMPUTE_F32
         if bf16:
+            dt = torch.float16 if bf16 == "f16" else torch.bfloat16
+            self.compute16 = capi.COMPUTE_F16 if bf16 == "f16" else capi.COMPUTE_BF16
             # [taps][cin_pad/8][wn][8]: a B fragment (8 consecutive k for one column) is one 16-byte read
-            t = torch.from_numpy(packed).to(torch.bfloat16).reshape(taps, self.cin_pad // 8, 8, self.wn).permute(0, 1, 3, 2).contiguous()
-            self.w_bf16 = t.to(device)
+            t = torch.from_numpy(packed).to(dt).reshape(taps, self.cin_pad // 8, 8, self.wn).permute(0, 1, 3, 2).contiguous()
+            self.w16 = t.to(device)
+        self.w_bf16 = self.w16  # (older name)
         self.bias = None if bias is None else torch.from_numpy(np.ascontiguousarray(bias, dtype=np.float32)).to(device)
 
 

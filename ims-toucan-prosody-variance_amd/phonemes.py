@@ -60,8 +60,10 @@ def phones_to_features(phones: str, handle_missing: bool = True) -> np.ndarray:
                 if not handle_missing:
                     raise KeyError(ch)
                 print("unknown phoneme: {}".format(ch))
-                continue
-            rows.append(vec.copy())
+            else:
+                rows.append(vec.copy())
+            # the reference consumes a pending stress mark here even when the symbol was unknown, so the stress then lands
+            # on the PREVIOUS phoneme (TextFrontend.py:275-286; an IndexError if there is none, as there)
             if stressed:
                 stressed = False
                 rows[-1][IDX["stressed"]] = 1.0

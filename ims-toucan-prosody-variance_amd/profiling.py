@@ -17,7 +17,8 @@ def kernel_class(cw, compute, tile_rows=None):
     bm, bn = cw.tile_rows, cw.n_tile
     if tile_rows is not None and tile_rows != cw.tile_rows:
         bm, bn = tile_rows, 64
-    return "conv1d_%s<%dx%d%s>" % ("bf16" if compute == capi.COMPUTE_BF16 else "f32", bm, bn, ",dual" if dual else "")
+    prec = {capi.COMPUTE_F32: "f32", capi.COMPUTE_BF16: "bf16", capi.COMPUTE_F16: "f16"}[compute]
+    return "conv1d_%s<%dx%d%s>" % (prec, bm, bn, ",dual" if dual else "")
 
 
 class ConvTimer:
@@ -32,29 +33,36 @@ class ConvTimer:
     def wants_name(self, name):
         return self.enabled and (self.select is None or name in self.select)
 
-    def add_named(self, name, flops, ev0, ev1):
-        self.records.append((name, flops, ev0, ev1))
+    def add_named(self, name, flops, ev0, ev1, nbytes=0.0, elems=0.0):
+        self.records.append((name, flops, ev0, ev1, nbytes, elems))
 
     def events(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def add(self, cw, compute, rows, ev0, ev1, tile_rows=None):
+    def add(self, cw, compute, rows, ev0, ev1, tile_rows=None, x_bytes=4, y_bytes=4):
+        """Algorithmic bytes of a conv launch: its input and output tensors once (in their HBM element size) + its weights once."""
         ctot = cw.cout * (2 if cw.mode != capi.MODE_LINEAR else 1)
         flops = 2.0 * rows * cw.cin * ctot * cw.algo_taps
-        self.records.append((kernel_class(cw, compute, tile_rows), flops, ev0, ev1))
+        wbytes = cw.taps * cw.cin * ctot * (4 if compute == capi.COMPUTE_F32 else 2)
+        nbytes = float(rows) * (cw.cin * x_bytes + cw.cout * y_bytes) + wbytes
+        self.records.append((kernel_class(cw, compute, tile_rows), flops, ev0, ev1, nbytes, float(rows) * cw.cout))
 
     def summary(self):
         """class -> dict(launches, total_ms, avg_us, flops_per_launch, tflops). Call after a device sync."""
         out = {}
-        for name, flops, e0, e1 in self.records:
+        for name, flops, e0, e1, nbytes, elems in self.records:
             ms = e0.elapsed_time(e1)
-            s = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0))
+            s = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, elems=0.0))
             s["launches"] += 1
             s["total_ms"] += ms
             s["flops"] += flops
+            s["bytes"] += nbytes
+            s["elems"] += elems
         for s in out.values():
             s["avg_us"] = 1e3 * s["total_ms"] / s["launches"]
             s["flops_per_launch"] = s["flops"] / s["launches"]
+            s["bytes_per_launch"] = s["bytes"] / s["launches"]
+            s["elems_per_launch"] = s["elems"] / s["launches"]
             s["tflops"] = s["flops"] / (s["total_ms"] * 1e-3) / 1e12 if s["total_ms"] > 0 else 0.0
         return out
 

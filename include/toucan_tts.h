@@ -52,6 +52,10 @@ typedef struct {
 #define TTS_IO_X_BF16 1
 #define TTS_IO_Y_BF16 2
 #define TTS_IO_RES_BF16 4
+#define TTS_IO_F16 8      /* the 16-bit tensors named by the three bits above are IEEE fp16 (compute 2) instead of bf16 */
+#define TTS_COMPUTE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation */
+#define TTS_COMPUTE_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulation (BASELINE.json configs[2]) */
+#define TTS_COMPUTE_F16 2  /* v_mfma_f32_32x32x16_f16, fp32 accumulation (BASELINE.json configs[4]) */
 #define TTS_PRE_NONE 0
 #define TTS_PRE_LRELU 1
 #define TTS_PRE_SNAKE 2 /* anti-aliased SnakeBeta (see tts_snake_aa) applied while the input window is staged */
@@ -83,8 +87,10 @@ typedef struct {
   const float* res;    int32_t ld_res; float res_scale;
   const float* aux;    int32_t ld_aux;    /* COUPLING: x1 */
   int32_t accumulate;
-  int32_t compute;     /* 0: fp32 MFMA (exact fp32 fma chain); 1: bf16 MFMA, fp32 accumulate */
-  int32_t io_flags;    /* TTS_IO_* bits: which of x / y / res are bf16 tensors in HBM (ld* then count bf16 elements) */
+  int32_t compute;     /* TTS_COMPUTE_*: 0 fp32 MFMA (exact fp32 fma chain); 1 bf16 MFMA; 2 fp16 MFMA (both fp32 accumulate);
+                          w must be packed in the matching element type */
+  int32_t io_flags;    /* TTS_IO_* bits: which of x / y / res are 16-bit tensors in HBM (ld* then count 16-bit elements) and
+                          whether those are bf16 or fp16 (TTS_IO_F16; a 16-bit compute mode only takes its own format) */
   const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows; /* tts_conv1d_tile_rows() or the small form's 64 */
 } TtsConvDesc;
 
@@ -99,13 +105,13 @@ int tts_conv1d_small_tile_rows(int32_t cout, int32_t mode, int32_t packed_cols);
 int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream);
 
 /*
- * Fused vocoder residual step (bf16 MFMA, fp32 accumulate, fp32 tensors in HBM):
+ * Fused vocoder residual step (bf16 or fp16 MFMA, fp32 accumulate; fp32 or 16-bit tensors in HBM):
  *   y = alpha * conv2(act(conv1(act(x)) + b1)) + b2) + res_scale * x   (+ y if accumulate)
  * conv1: `taps` taps, dilation `dil`; conv2: `taps` taps, dilation 1; both C -> C, 'same' zero padding per utterance.
  * act = TTS_PRE_LRELU (slope) or TTS_PRE_SNAKE (anti-aliased SnakeBeta with (alpha1,beta1) / (alpha2,beta2), filter [12]).
  * Replaces one dilation step of BigVGAN/AMP.py:53-58 (a1, c1, a2, c2, + x) or Layers/ResidualBlock.py:93-97; with
  * alpha = res_scale = 1/3 and accumulate it also forms the stage mean of InferenceBigVGAN.py:82-88.
- * Weights: bf16 [taps][C/8][C][8] as produced for tts_conv1d(compute = 1).  C in {32, 64, 128, 256}.
+ * Weights: bf16 / fp16 [taps][C/8][C][8] as produced for tts_conv1d(compute = 1 / 2).  C in {32, 64, 128, 256}.
  */
 typedef struct {
   const float* x; int32_t ldx;
@@ -116,8 +122,9 @@ typedef struct {
   int32_t act; float slope;
   const float* alpha1; const float* beta1; const float* alpha2; const float* beta2; const float* filt;
   float alpha, res_scale; int32_t accumulate;
-  int32_t io_bf16; /* 1: x and y are bf16 tensors in HBM (halves the traffic of this bandwidth-bound step) */
+  int32_t io_bf16; /* 1: x and y are 16-bit tensors in HBM, in the format of `compute` (halves the traffic of this bandwidth-bound step) */
   const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows;
+  int32_t compute; /* TTS_COMPUTE_BF16 or TTS_COMPUTE_F16: element format of the weights, the LDS tiles and 16-bit x / y */
 } TtsResblockDesc;
 
 /* rows per tile the fused step uses for C channels (224 for C <= 128, 96 for C = 256): build the tile table with it */
@@ -197,13 +204,13 @@ int tts_glow_invconv_actnorm(float* x, int32_t ldx, int32_t rows, int32_t c, con
  * BigVGAN/Snake.py:56-69 + alias_free_torch Activation1d (third party, PARITY UNPINNED - see DESIGN.md). */
 int tts_snake_aa(const float* x, int32_t ldx, float* y, int32_t ldy, const float* alpha, const float* beta,
                  const float* filt /*[12]*/, int32_t c, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
-                 int32_t io_flags /* TTS_IO_X_BF16 | TTS_IO_Y_BF16 */, tts_stream_t stream);
+                 int32_t io_flags /* TTS_IO_X_BF16 | TTS_IO_Y_BF16 | TTS_IO_F16 */, tts_stream_t stream);
 
 /* Final vocoder conv: wav[r] = tanh(b + sum_j sum_ci pre(x[r+j-3, ci]) w[j][ci]); pre = LeakyReLU(slope) or none.
  * InferenceAvocodo.py:52-59, InferenceBigVGAN.py:92-95. */
 int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w /*[7][cin]*/, float bias, int32_t pre_act,
                   float pre_slope, float* wav, const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows,
-                  int32_t io_flags /* TTS_IO_X_BF16 */, tts_stream_t stream);
+                  int32_t io_flags /* TTS_IO_X_BF16 | TTS_IO_F16 */, tts_stream_t stream);
 
 /* BigVGAN's last two ops in one launch: anti-aliased SnakeBeta (activation_post) then the 7-tap output conv + tanh
  * (InferenceBigVGAN.py:90-95).  The activated tensor exists only in LDS.  cin must be 32; tile_rows must be
@@ -211,7 +218,7 @@ int tts_conv_post(const float* x, int32_t ldx, int32_t cin, const float* w /*[7]
 int tts_conv_post_snake_tile_rows(void);
 int tts_conv_post_snake(const float* x, int32_t ldx, int32_t cin, const float* w /*[7][cin]*/, float bias, const float* alpha,
                         const float* beta, const float* filt /*[12]*/, float* wav, const TtsTile* tiles, int32_t n_tiles,
-                        int32_t tile_rows, int32_t io_flags /* TTS_IO_X_BF16 */, tts_stream_t stream);
+                        int32_t tile_rows, int32_t io_flags /* TTS_IO_X_BF16 | TTS_IO_F16 */, tts_stream_t stream);
 
 /* Elementwise helper: y = a*x + b*z (z may be NULL), rows x c with strides. */
 int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz, float b, float* y, int32_t ldy,
@@ -224,7 +231,7 @@ int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float*
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 6
+#define TTS_ABI_VERSION 7
 int tts_abi_version(void);
 
 #ifdef __cplusplus

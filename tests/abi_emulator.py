@@ -51,16 +51,37 @@ def _bf16_round(a):
     return r.astype(np.uint32).view(np.float32)
 
 
-def _load(ptr, r0, r1, cols, ld, bf16=False):
-    """rows [r0, r1) of a strided tensor as float32 (bf16 tensors are widened)."""
+def _round16(a, f16):
+    """round-to-nearest-even to bf16 (or IEEE fp16 when `f16`), returned as float32."""
+    if f16:
+        return np.ascontiguousarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+    return _bf16_round(a)
+
+
+def _widen16(raw, f16):
+    raw = np.ascontiguousarray(raw)
+    if f16:
+        return raw.view(np.float16).astype(np.float32)
+    return (raw.astype(np.uint32) << 16).view(np.float32)
+
+
+def _fmt(is16, f16):
+    """tensor format code: 0 fp32, 1 bf16, 2 fp16."""
+    return 0 if not is16 else (2 if f16 else 1)
+
+
+def _load(ptr, r0, r1, cols, ld, bf16=0):
+    """rows [r0, r1) of a strided tensor as float32 (16-bit tensors are widened; bf16 = 0 fp32 / 1 bf16 / 2 fp16)."""
     if bf16:
         raw = _mat(ptr, r1, cols, ld, np.uint16)[r0:r1]
-        return (raw.astype(np.uint32) << 16).view(np.float32)
+        return _widen16(raw, bf16 == 2).reshape(r1 - r0, cols)
     return _mat(ptr, r1, cols, ld)[r0:r1].astype(np.float32)
 
 
-def _store(ptr, r0, r1, cols, ld, values, bf16=False):
-    if bf16:
+def _store(ptr, r0, r1, cols, ld, values, bf16=0):
+    if bf16 == 2:
+        _mat(ptr, r1, cols, ld, np.uint16)[r0:r1] = np.ascontiguousarray(values, dtype=np.float32).astype(np.float16).view(np.uint16)
+    elif bf16:
         v = _bf16_round(np.ascontiguousarray(values, dtype=np.float32))
         _mat(ptr, r1, cols, ld, np.uint16)[r0:r1] = (v.view(np.uint32) >> 16).astype(np.uint16)
     else:
@@ -119,22 +140,24 @@ class Emulator:
         d = dref._obj
         t = _tiles(d.tiles, d.n_tiles)
         dual = d.mode != capi.MODE_LINEAR
-        if d.compute == capi.COMPUTE_BF16:
+        f16 = bool(d.io_flags & capi.IO_F16) or d.compute == capi.COMPUTE_F16
+        fx, fy, fr = (_fmt(d.io_flags & b, f16) for b in (capi.IO_X_BF16, capi.IO_Y_BF16, capi.IO_RES_BF16))
+        if d.compute != capi.COMPUTE_F32:
             wraw = _arr(d.w, d.taps * d.cin_pad * d.wn, np.uint16).reshape(d.taps, d.cin_pad // 8, d.wn, 8)
-            w = (wraw.astype(np.uint32) << 16).view(np.float32).transpose(0, 1, 3, 2).reshape(d.taps, d.cin_pad, d.wn)
+            w = _widen16(wraw, d.compute == capi.COMPUTE_F16).reshape(wraw.shape).transpose(0, 1, 3, 2).reshape(d.taps, d.cin_pad, d.wn)
         else:
             w = _arr(d.w, d.taps * d.cin_pad * d.wn).reshape(d.taps, d.cin_pad, d.wn)
         bias = _arr(d.bias, d.cout * (2 if dual else 1)) if d.bias else None
         for sb, se, sid in _seqs_from_tiles(t):
             n = se - sb
-            x = _load(d.x, sb, se, d.cin, d.ldx, d.io_flags & capi.IO_X_BF16)
+            x = _load(d.x, sb, se, d.cin, d.ldx, fx)
             if d.pre_act == capi.PRE_LRELU:
                 x = np.where(x > 0, x, x * np.float32(d.pre_slope))
             elif d.pre_act == capi.PRE_SNAKE:
                 x = _snake_seq(x.astype(np.float64), _arr(d.snake_alpha, d.cin), _arr(d.snake_beta, d.cin),
                                _arr(d.snake_filt, 12)).astype(np.float32)
-            if d.compute == capi.COMPUTE_BF16:
-                x = _bf16_round(x)
+            if d.compute != capi.COMPUTE_F32:
+                x = _round16(x, d.compute == capi.COMPUTE_F16)
             halo = (d.taps - 1) * d.dil
             xp = np.zeros((n + halo, d.cin), dtype=np.float32)
             xp[d.pad_left:d.pad_left + n] = x
@@ -170,10 +193,10 @@ class Emulator:
                     v = np.tanh(v.astype(np.float64))
             v = (np.asarray(v, dtype=np.float32) * np.float32(d.alpha)).astype(np.float32)
             if d.res:
-                v = v + np.float32(d.res_scale) * _load(d.res, sb, se, d.cout, d.ld_res, d.io_flags & capi.IO_RES_BF16)
+                v = v + np.float32(d.res_scale) * _load(d.res, sb, se, d.cout, d.ld_res, fr)
             if d.accumulate:
-                v = v + _load(d.y, sb, se, d.cout, d.ldy, d.io_flags & capi.IO_Y_BF16)
-            _store(d.y, sb, se, d.cout, d.ldy, v, d.io_flags & capi.IO_Y_BF16)
+                v = v + _load(d.y, sb, se, d.cout, d.ldy, fy)
+            _store(d.y, sb, se, d.cout, d.ldy, v, fy)
         return 0
 
     def tts_resblock_tile_rows(self, c):
@@ -186,9 +209,13 @@ class Emulator:
         d = dref._obj
         C_, k = d.c, d.taps
 
+        f16 = d.compute == capi.COMPUTE_F16
+        io = _fmt(d.io_bf16, f16)
+        rnd = lambda a: _round16(a, f16)
+
         def wload(ptr):
             raw = _arr(ptr, k * C_ * C_, np.uint16).reshape(k, C_ // 8, C_, 8)
-            return (raw.astype(np.uint32) << 16).view(np.float32).transpose(0, 1, 3, 2).reshape(k, C_, C_).astype(np.float64)
+            return _widen16(raw, f16).reshape(raw.shape).transpose(0, 1, 3, 2).reshape(k, C_, C_).astype(np.float64)
 
         w1, w2 = wload(d.w1), wload(d.w2)
         b1, b2 = _arr(d.b1, C_).astype(np.float64), _arr(d.b2, C_).astype(np.float64)
@@ -208,18 +235,18 @@ class Emulator:
             return sum(vp[j * dil:j * dil + n] @ w[j] for j in range(k))
 
         for sb, se, sid in _seqs_from_tiles(_tiles(d.tiles, d.n_tiles)):
-            x = _load(d.x, sb, se, C_, d.ldx, d.io_bf16).astype(np.float64)
-            a1 = _bf16_round(act(x, d.alpha1, d.beta1).astype(np.float32)).astype(np.float64)
+            x = _load(d.x, sb, se, C_, d.ldx, io).astype(np.float64)
+            a1 = rnd(act(x, d.alpha1, d.beta1).astype(np.float32)).astype(np.float64)
             t = conv(a1, w1, d.dil) + b1
             if snake:
-                t = _bf16_round(t.astype(np.float32)).astype(np.float64)
-                a2 = _bf16_round(act(t, d.alpha2, d.beta2).astype(np.float32)).astype(np.float64)
+                t = rnd(t.astype(np.float32)).astype(np.float64)
+                a2 = rnd(act(t, d.alpha2, d.beta2).astype(np.float32)).astype(np.float64)
             else:
-                a2 = _bf16_round(act(t, None, None).astype(np.float32)).astype(np.float64)
+                a2 = rnd(act(t, None, None).astype(np.float32)).astype(np.float64)
             v = np.float32(d.alpha) * (conv(a2, w2, 1) + b2).astype(np.float32) + np.float32(d.res_scale) * x.astype(np.float32)
             if d.accumulate:
-                v = v + _load(d.y, sb, se, C_, d.ldy, d.io_bf16)
-            _store(d.y, sb, se, C_, d.ldy, v.astype(np.float32), d.io_bf16)
+                v = v + _load(d.y, sb, se, C_, d.ldy, io)
+            _store(d.y, sb, se, C_, d.ldy, v.astype(np.float32), io)
         return 0
 
     def tts_layernorm(self, x, ldx, y, ldy, gamma, beta, rows, c, eps, stream):
@@ -389,9 +416,9 @@ class Emulator:
     def tts_snake_aa(self, x, ldx, y, ldy, alpha, beta, filt, c, tiles, n_tiles, tile_rows, io_flags, stream):
         self._count("snake_aa")
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
-            X = _load(x, sb, se, c, ldx, io_flags & capi.IO_X_BF16).astype(np.float64)
+            X = _load(x, sb, se, c, ldx, _fmt(io_flags & capi.IO_X_BF16, io_flags & capi.IO_F16)).astype(np.float64)
             out = _snake_seq(X, _arr(alpha, c), _arr(beta, c), _arr(filt, 12)).astype(np.float32)
-            _store(y, sb, se, c, ldy, out, io_flags & capi.IO_Y_BF16)
+            _store(y, sb, se, c, ldy, out, _fmt(io_flags & capi.IO_Y_BF16, io_flags & capi.IO_F16))
         return 0
 
     def tts_conv_post(self, x, ldx, cin, w, bias, pre_act, pre_slope, wav, tiles, n_tiles, tile_rows, io_flags, stream):
@@ -399,7 +426,7 @@ class Emulator:
         W = _mat(w, 7, cin, cin).astype(np.float64)
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
             n = se - sb
-            X = _load(x, sb, se, cin, ldx, io_flags & capi.IO_X_BF16).astype(np.float64)
+            X = _load(x, sb, se, cin, ldx, _fmt(io_flags & capi.IO_X_BF16, io_flags & capi.IO_F16)).astype(np.float64)
             if pre_act == capi.PRE_LRELU:
                 X = np.where(X > 0, X, X * pre_slope)
             xp = np.zeros((n + 6, cin))
@@ -416,7 +443,7 @@ class Emulator:
         W = _mat(w, 7, cin, cin).astype(np.float64)
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
             n = se - sb
-            X = _load(x, sb, se, cin, ldx, io_flags & capi.IO_X_BF16).astype(np.float64)
+            X = _load(x, sb, se, cin, ldx, _fmt(io_flags & capi.IO_X_BF16, io_flags & capi.IO_F16)).astype(np.float64)
             X = _snake_seq(X, _arr(alpha, cin), _arr(beta, cin), _arr(filt, 12))
             xp = np.zeros((n + 6, cin))
             xp[3:3 + n] = X

@@ -32,6 +32,8 @@ STRINGS = [
     "~#",
     "ɡ g ʔ ǀ ǁ ǂ ǃ ʘ",
     "a\u0303 e\u0306 oː\u0303",      # combining tilde / breve (decomposed forms are the ones the table knows)
+    "aˈ§bˈi",                     # a stress mark followed by an unknown symbol: the stress lands on the PREVIOUS phoneme (:282-286)
+    "tˈ€ˈ$oː",                    # twice in a row, then a modifier on the following known phoneme
 ]
 LANGS = ["de", "el", "es", "fi", "ru", "hu", "nl", "fr", "pt", "pl", "it", "en", "cmn", "vi", "uk", "fa", "pt-br", "xx"]
 

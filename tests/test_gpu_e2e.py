@@ -173,6 +173,95 @@ def test_bf16_acoustic_within_stated_tolerance():
     assert err.mean() < 0.05, float(err.mean())
 
 
+def _configs2_batch(B=32, L=128):
+    """configs[2] / configs[4] shape: B utterances x 128 phonemes, gold durations.  Utterance 0 is the reference golden
+    L128_gold5 (565 frames), the others are the seeded synthetic utterances of bench.py (5 frames per phoneme -> 640 frames)."""
+    g = _gold("L128_gold5")
+    texts = [torch.from_numpy(g["text"])] + [torch.from_numpy(syn.utterance_features(u, L, word_boundaries=False)) for u in range(1, B)]
+    embs = torch.stack([torch.from_numpy(g["utt_emb"])] + [torch.from_numpy(syn.utterance_embedding(u)) for u in range(1, B)])
+    durs = [torch.from_numpy(g["gold_durations"]).to(torch.int32)] + [torch.full((L,), 5, dtype=torch.int32) for _ in range(1, B)]
+    zs = [torch.from_numpy(g["z"])] + [torch.from_numpy(syn.postflow_noise(u, 5 * L)) for u in range(1, B)]
+    return g, texts, embs, durs, zs
+
+
+# Stated tolerances of the 16-bit configurations against the fp32 reference golden L128_gold5 (|mel| mean 4.1, max 63; |wav| <= 1).
+# mel: mean-abs error; wav: mean-abs error of the vocoder alone on the golden mel (head and tail 8192 samples).
+# Measured on MI355X (this test prints them, DESIGN.md section 4 records them): see MEASURED_16BIT in DESIGN.md.
+TOL_16BIT = {"bf16": dict(mel_mean=0.05, wav_mean=2e-2), "f16": dict(mel_mean=0.01, wav_mean=4e-3)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_full_size_batch32_16bit_bigvgan_equals_per_utterance_runs(precision):
+    """BASELINE.json configs[2] (bf16) and the single-GPU shard of configs[4] (fp16, pitch 1.3 / energy 0.7) at FULL size:
+    batch 32 x 128 phonemes, 16-bit acoustic MFMA + 16-bit BigVGAN with fused residual steps and a 16-bit residual stream.
+    (1) every utterance of the batch is BIT-IDENTICAL (mel and waveform) to the same utterance run alone (B = 1): batching
+        never changes an utterance's arithmetic (same kernels, same K order, per-utterance tiles);
+    (2) utterance 0 stays within the stated tolerance of the fp32 reference golden (mel), and the vocoder alone - fed the golden
+        mel as utterance 0 of a 32-batch - within the stated waveform tolerance.  The measured errors are printed and written
+        to gpurun_out/parity_16bit_<precision>.json."""
+    g, texts, embs, durs, zs = _configs2_batch()
+    B = len(texts)
+    langs = [int(g["lang_id"])] * B
+    kw = dict(pitch_variance_scale=1.3, energy_variance_scale=0.7) if precision == "f16" else {}
+    ac = engine.AcousticEngine(fw.acoustic_state_dict(), DEV, precision=precision)
+    voc = engine.VocoderEngine(fw.bigvgan_state_dict(), "bigvgan", DEV, precision=precision)
+    assert voc.fuse_step and voc.store_bf16
+    out = ac.forward(texts, embs, langs, durations=durs, z_noise=zs, **kw)
+    wav, rw = voc.forward(out["mel_packed"], out["rag_mel"])
+    mels = [m.clone() for m in out["mel"]]
+    wavs = [wav[b:b + n].clone() for b, n in zip(rw.begins, rw.lengths)]
+    pitch_b = [p.clone() for p in out["pitch"]]
+    for u in range(B):
+        o1 = ac.forward([texts[u]], embs[u:u + 1], [langs[u]], durations=[durs[u]], z_noise=[zs[u]], **kw)
+        w1, r1 = voc.forward(o1["mel_packed"], o1["rag_mel"])
+        assert torch.equal(o1["pitch"][0], pitch_b[u]), f"utterance {u}: pitch differs between B=32 and B=1"
+        assert torch.equal(o1["mel"][0], mels[u]), f"utterance {u}: mel differs between B=32 and B=1 (max {float((o1['mel'][0] - mels[u]).abs().max()):.3e})"
+        assert torch.equal(w1[: r1.lengths[0]], wavs[u]), f"utterance {u}: waveform differs between B=32 and B=1"
+    rec = {"precision": precision, "batch": B}
+    if precision == "bf16":  # the golden was captured without prosody scaling
+        err = np.abs(mels[0].cpu().numpy() - g["mel"])
+        rec.update(mel_mean_abs=float(err.mean()), mel_max_abs=float(err.max()), mel_ref_mean_abs=float(np.abs(g["mel"]).mean()))
+        assert err.mean() < TOL_16BIT[precision]["mel_mean"], rec
+    else:
+        o0 = ac.forward([texts[0]], embs[:1], [langs[0]], durations=[durs[0]], z_noise=[zs[0]])
+        err = np.abs(o0["mel"][0].cpu().numpy() - g["mel"])
+        rec.update(mel_mean_abs=float(err.mean()), mel_max_abs=float(err.max()), mel_ref_mean_abs=float(np.abs(g["mel"]).mean()))
+        assert err.mean() < TOL_16BIT[precision]["mel_mean"], rec
+    # vocoder alone on the golden mel, inside the full batch
+    mp = out["mel_packed"].clone()
+    rm = out["rag_mel"]
+    mp[rm.begins[0]:rm.begins[0] + rm.lengths[0]] = torch.from_numpy(g["mel"]).to(DEV)
+    wav2, rw2 = voc.forward(mp, rm)
+    w0 = wav2[rw2.begins[0]:rw2.begins[0] + rw2.lengths[0]].cpu().numpy()
+    assert w0.shape[0] == int(g["wav_len"])
+    eh, et = np.abs(w0[:8192] - g["wav_bigvgan_head"]), np.abs(w0[-8192:] - g["wav_bigvgan_tail"])
+    rec.update(wav_mean_abs=float((eh.mean() + et.mean()) / 2), wav_max_abs=float(max(eh.max(), et.max())),
+               wav_ref_mean_abs=float(np.abs(g["wav_bigvgan_head"]).mean()))
+    print("16-bit parity at full size:", json.dumps(rec))
+    os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", f"parity_16bit_{precision}.json"), "w") as f:
+        json.dump(rec, f)
+    assert rec["wav_mean_abs"] < TOL_16BIT[precision]["wav_mean"], rec
+
+
+def test_fp16_configuration_within_stated_tolerance():
+    """configs[4] precision (fp16 MFMA GEMMs, fp32 statistics / flow state) on the small goldens: acoustic mel and both vocoders."""
+    g = _gold("L20_pred")
+    ac = engine.AcousticEngine(fw.acoustic_state_dict(), DEV, precision="f16")
+    texts, embs, langs, zs = _inputs([g])
+    out = ac.forward(texts, embs, langs, z_noise=zs, durations=[torch.from_numpy(g["durations"])])
+    err = np.abs(out["mel"][0].cpu().numpy() - g["mel"])
+    print("fp16 acoustic: mel mean abs err", float(err.mean()), "max", float(err.max()))
+    assert err.mean() < TOL_16BIT["f16"]["mel_mean"]
+    mel = torch.from_numpy(g["mel"]).to(DEV).contiguous()
+    for kind, sd in (("hifigan", fw.hifigan_state_dict()), ("bigvgan", fw.bigvgan_state_dict())):
+        voc = engine.VocoderEngine(sd, kind, DEV, precision="f16")
+        wav, _ = voc.forward(mel, Ragged([mel.shape[0]], DEV))
+        e = np.abs(wav.cpu().numpy() - g["wav_" + kind])
+        print("fp16", kind, "wav mean abs err", float(e.mean()), "max", float(e.max()))
+        assert e.mean() < TOL_16BIT["f16"]["wav_mean"], (kind, float(e.mean()))
+
+
 def test_hip_graph_replay_is_bit_identical_to_eager():
     """use_graphs: the two shape-static halves of the acoustic pass and the vocoder are captured and replayed."""
     g = _gold("L20_pred")
@@ -191,6 +280,33 @@ def test_hip_graph_replay_is_bit_identical_to_eager():
         assert torch.equal(out["durations_packed"], ref["durations_packed"])
         assert torch.equal(w[:n], wref[:n])  # rows beyond the utterance are alignment padding (never written)
     _check_mel(out["mel"][0], g, "graph replay")
+
+
+def test_hip_graphs_survive_table_regrowth_and_layout_cache_turnover():
+    """Graph replay after the buffers a capture read by raw pointer were replaced: a short utterance, then one with more than 256
+    frames (the relative-position tables regrow and are re-allocated), then the short one again - and the same after Ragged's
+    layout cache was emptied.  Replays must equal the eager result bit for bit (stale tables / freed tile tables would not)."""
+    from ims_toucan_prosody_variance_amd import ragged
+    gs, gl = _gold("L20_pred"), _gold("L128_gold5")
+    eager = engine.AcousticEngine(fw.acoustic_state_dict(), DEV)
+    graphed = engine.AcousticEngine(fw.acoustic_state_dict(), DEV, use_graphs=True)
+
+    def run(eng, g):
+        texts, embs, langs, zs = _inputs([g])
+        kw = {"durations": [torch.from_numpy(g["gold_durations"])]} if "gold_durations" in g.files else {}
+        return eng.forward(texts, embs, langs, z_noise=zs, **kw)["mel"][0].clone()
+
+    ref_s, ref_l = run(eager, gs), run(eager, gl)
+    assert torch.equal(run(graphed, gs), ref_s)      # captures with pmax = 256
+    assert torch.equal(run(graphed, gl), ref_l)      # 565 frames: tables regrow
+    assert torch.equal(run(graphed, gs), ref_s)      # must not replay against the released tables
+    assert torch.equal(run(graphed, gs), ref_s)      # (replay of the re-captured graph)
+    ragged.Ragged._cache.clear()                     # the layouts the graphs captured leave the cache ...
+    junk = [torch.empty(1 << 20, device=DEV) for _ in range(8)]  # ... and freed blocks would be handed out again
+    for j in junk:
+        j.fill_(1e30)
+    assert torch.equal(run(graphed, gl), ref_l)
+    assert torch.equal(run(graphed, gs), ref_s)
 
 
 def test_drop_in_interface_on_the_gpu(tmp_path, monkeypatch):

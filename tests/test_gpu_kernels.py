@@ -23,9 +23,7 @@ def gpu():
 
 @pytest.fixture(scope="module")
 def cpu():
-    ops = engine.Ops("cpu")
-    ops.lib = abi_emulator.Emulator()
-    return ops
+    return engine.Ops("cpu", lib=abi_emulator.Emulator())
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -38,6 +36,12 @@ def close(a, b, tol=2e-5):
     scale = max(1.0, float(np.abs(b).max()))
     err = float(np.abs(a - b).max())
     assert err <= tol * scale, f"max abs err {err:.3e} vs tol {tol * scale:.3e}"
+
+
+PACK16 = {capi.COMPUTE_F32: True, capi.COMPUTE_BF16: "bf16", capi.COMPUTE_F16: "f16"}  # pack_conv's 16-bit copy per compute mode
+DT16 = {capi.COMPUTE_BF16: torch.bfloat16, capi.COMPUTE_F16: torch.float16}
+TOL = {capi.COMPUTE_F32: 2e-5, capi.COMPUTE_BF16: 2e-2, capi.COMPUTE_F16: 3e-3}  # relative to the output scale
+ALL_COMPUTE = [capi.COMPUTE_F32, capi.COMPUTE_BF16, capi.COMPUTE_F16]
 
 
 def both(gpu, cpu, fn):
@@ -71,7 +75,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", CONV_CASES)
-@pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
+@pytest.mark.parametrize("compute", ALL_COMPUTE)
 @pytest.mark.parametrize("form", ["regular", "small"])
 def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
     # form: the regular 128/256-row tiles, or the 64 x 64 small-batch tiles the host picks when the grid is small
@@ -86,7 +90,7 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
     def run(ops, to):
         rag = Ragged(lengths, ops.device, align=2)
         R = rag.total_rows
-        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode, bf16=True)
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode, bf16=PACK16[compute])
         x = to(rnd(R, cin + 3, seed=3))[:, :cin]  # strided input view
         y = to(rnd(R, co + 5, seed=4))
         res = to(rnd(R, co, seed=5))
@@ -101,11 +105,11 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
         g, c = both(gpu, cpu, run)
     finally:
         gpu.small_tile_blocks = 1536
-    close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
+    close(g, c, TOL[compute])
 
 
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 257]), (64, 11, 5, [300, 40]), (256, 7, 3, [130, 1, 2]), (128, 3, 5, [64, 8])])
-@pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
+@pytest.mark.parametrize("compute", ALL_COMPUTE)
 def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compute):
     """TTS_PRE_SNAKE: the conv's input staging applies Activation1d(SnakeBeta) (AMP.py:53-56) - ragged edges included."""
     w = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
@@ -114,7 +118,7 @@ def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compu
     def run(ops, to):
         rag = Ragged(lengths, ops.device, align=2)
         R = rag.total_rows
-        cw = packing.pack_conv(w, b, ops.device, dil=dil, bf16=True)
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, bf16=PACK16[compute])
         x = to(rnd(R, c, seed=3))
         y = to(torch.zeros(R, c))
         res = to(rnd(R, c, seed=5))
@@ -122,16 +126,18 @@ def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compu
         return ops.conv(cw, x, y, rag, pre=capi.PRE_SNAKE, snake=sn, res=res, compute=compute)
 
     g, cc = both(gpu, cpu, run)
-    close(g, cc, 3e-5 if compute == capi.COMPUTE_F32 else 2e-2)
+    close(g, cc, 3e-5 if compute == capi.COMPUTE_F32 else TOL[compute])
 
 
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 225]), (32, 11, 5, [700, 30]), (64, 7, 3, [224, 449, 1]), (64, 11, 5, [300]),
                                              (128, 3, 1, [500, 17]), (128, 11, 5, [260, 100]), (128, 7, 1, [2, 223]),
                                              (256, 3, 1, [200, 97]), (256, 11, 5, [130, 96, 1]), (256, 7, 3, [95])])
 @pytest.mark.parametrize("act", [capi.PRE_LRELU, capi.PRE_SNAKE])
-@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16])
-def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act, store):
-    """tts_resblock_step against the emulator (same bf16 rounding points) on ragged batches incl. tile-boundary lengths."""
+@pytest.mark.parametrize("store,compute", [(torch.float32, capi.COMPUTE_BF16), (torch.bfloat16, capi.COMPUTE_BF16),
+                                           (torch.float32, capi.COMPUTE_F16), (torch.float16, capi.COMPUTE_F16)])
+def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act, store, compute):
+    """tts_resblock_step against the emulator (same 16-bit rounding points) on ragged batches incl. tile-boundary lengths,
+    in both 16-bit formats (bf16 MFMA / fp16 MFMA) with fp32 or 16-bit tensors in HBM."""
     w1 = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
     w2 = rnd(c, c, k, seed=2, scale=1.0 / np.sqrt(c * k)).numpy()
     b1, b2 = rnd(c, seed=3, scale=0.1).numpy(), rnd(c, seed=4, scale=0.1).numpy()
@@ -139,8 +145,8 @@ def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act, store):
     def run(ops, to):
         rag = Ragged(lengths, ops.device, align=2)
         R = rag.total_rows
-        c1 = packing.pack_conv(w1, b1, ops.device, dil=dil, bf16=True)
-        c2 = packing.pack_conv(w2, b2, ops.device, dil=1, bf16=True)
+        c1 = packing.pack_conv(w1, b1, ops.device, dil=dil, bf16=PACK16[compute])
+        c2 = packing.pack_conv(w2, b2, ops.device, dil=1, bf16=PACK16[compute])
         x = to(rnd(R, c, seed=5).to(store))
         y = to(rnd(R, c, seed=6).to(store))
         sn1 = (to(rnd(c, seed=7, scale=0.3)), to(rnd(c, seed=8, scale=0.3)))
@@ -149,30 +155,38 @@ def test_fused_resblock_step(gpu, cpu, c, k, dil, lengths, act, store):
         return ops.resblock_step(c1, c2, x, y, rag, act, 0.1, sn1, sn2, filt, alpha=1.0 / 3.0, res_scale=1.0 / 3.0, accumulate=True)
 
     g, cc = both(gpu, cpu, run)
-    close(g, cc, 1e-2 if store == torch.float32 else 2e-2)
+    if compute == capi.COMPUTE_F16:
+        close(g, cc, 2e-3 if store == torch.float32 else 3e-3)
+    else:
+        close(g, cc, 1e-2 if store == torch.float32 else 2e-2)
 
 
-def test_conv1d_bf16_tensors_in_hbm(gpu, cpu):
-    """TTS_IO_*_BF16: x / y / res stored as bf16 (transposed-conv outputs and residual streams of the bf16 vocoder)."""
+@pytest.mark.parametrize("compute", [capi.COMPUTE_BF16, capi.COMPUTE_F16])
+def test_conv1d_bf16_tensors_in_hbm(gpu, cpu, compute):
+    """TTS_IO_*_BF16 (+ TTS_IO_F16): x / y / res stored as 16-bit tensors (transposed-conv outputs and residual streams of the
+    bf16 / fp16 vocoder)."""
+    dt = DT16[compute]
     w = rnd(64, 64, 3, seed=1, scale=0.1).numpy()
 
     def run(ops, to):
         rag = Ragged([300, 17], ops.device, align=2)
         R = rag.total_rows
-        cw = packing.pack_conv(w, rnd(64, seed=2, scale=0.1).numpy(), ops.device, bf16=True)
-        x = to(rnd(R, 64, seed=3).to(torch.bfloat16))
-        y = to(rnd(R, 64, seed=4).to(torch.bfloat16))
-        res = to(rnd(R, 64, seed=5).to(torch.bfloat16))
+        cw = packing.pack_conv(w, rnd(64, seed=2, scale=0.1).numpy(), ops.device, bf16=PACK16[compute])
+        x = to(rnd(R, 64, seed=3).to(dt))
+        y = to(rnd(R, 64, seed=4).to(dt))
+        res = to(rnd(R, 64, seed=5).to(dt))
         sn = (to(rnd(64, seed=6, scale=0.3)), to(rnd(64, seed=7, scale=0.3)), to(torch.from_numpy(packing.kaiser_sinc_filter12())))
-        ops.conv(cw, x, y, rag, pre=capi.PRE_SNAKE, snake=sn, res=res, accumulate=True, compute=capi.COMPUTE_BF16)
+        ops.conv(cw, x, y, rag, pre=capi.PRE_SNAKE, snake=sn, res=res, accumulate=True, compute=compute)
         y2 = to(torch.zeros(R, 64))
-        ops.conv(cw, x, y2, rag, pre=capi.PRE_LRELU, pre_slope=0.1, res=res, compute=capi.COMPUTE_BF16)  # bf16 in, fp32 out
+        ops.conv(cw, x, y2, rag, pre=capi.PRE_LRELU, pre_slope=0.1, res=res, compute=compute)  # 16-bit in, fp32 out
         s_out = to(torch.zeros(R, 64))
         ops.snake_aa(x, s_out, sn[0], sn[1], sn[2], 64, rag)
-        return torch.cat([y.float(), y2, s_out])
+        s16 = to(torch.zeros(R, 64, dtype=dt))
+        ops.snake_aa(x, s16, sn[0], sn[1], sn[2], 64, rag)  # 16-bit in, 16-bit out
+        return torch.cat([y.float(), y2, s_out, s16.float()])
 
     g, cc = both(gpu, cpu, run)
-    close(g, cc, 2e-2)
+    close(g, cc, TOL[compute])
 
 
 def test_conv1d_rows_outside_utterances_are_untouched(gpu):
@@ -344,7 +358,7 @@ def test_library_rejects_bad_arguments(gpu):
     (192, 256, 3, 1, capi.MODE_LINEAR, [64, 3, 129]),
     (256, 256, 5, 2, capi.MODE_LINEAR, [7, 1, 40]),
 ])
-@pytest.mark.parametrize("compute", [capi.COMPUTE_F32, capi.COMPUTE_BF16])
+@pytest.mark.parametrize("compute", ALL_COMPUTE)
 def test_conv1d_rows_kernel(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, monkeypatch):
     """1-tap convs with 16-byte aligned contiguous rows take the LDS-free kernel in the small-batch form (fp32 always, bf16 on
     latency-bound grids or when TOUCAN_GEMM_ROWS_BF16 is set); the multi-tap cases run the LDS-staged small form on the same
@@ -358,7 +372,7 @@ def test_conv1d_rows_kernel(gpu, cpu, cin, cout, k, dil, mode, lengths, compute,
     def run(ops, to):
         rag = Ragged(lengths, ops.device, align=2)
         R = rag.total_rows
-        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode, bf16=True)
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode, bf16=PACK16[compute])
         x = to(rnd(R, cin, seed=3))
         y = to(rnd(R, co, seed=4))
         res = to(rnd(R, co, seed=5))
@@ -373,7 +387,7 @@ def test_conv1d_rows_kernel(gpu, cpu, cin, cout, k, dil, mode, lengths, compute,
         g, c = both(gpu, cpu, run)
     finally:
         gpu.small_tile_blocks = 1536
-    close(g, c, 2e-5 if compute == capi.COMPUTE_F32 else 2e-2)
+    close(g, c, TOL[compute])
 
 
 @pytest.mark.parametrize("n_seq,n_mlp,d_in,d_out", [(1, 24, 64, 256), (5, 3, 64, 256), (32, 24, 64, 256), (2, 2, 32, 48)])
@@ -394,8 +408,9 @@ def test_cln_mlp(gpu, cpu, n_seq, n_mlp, d_in, d_out):
 
 @pytest.mark.parametrize("cin,cout,mode,lengths", [(1536, 192, capi.MODE_LINEAR, [130, 7]), (192, 384, capi.MODE_GLU, [33]), (256, 256, capi.MODE_LINEAR, [1, 1])])
 @pytest.mark.parametrize("pre", [capi.PRE_NONE, capi.PRE_LRELU])
-def test_conv1d_rows_kernel_bf16_input(gpu, cpu, cin, cout, mode, lengths, pre, monkeypatch):
-    """The LDS-free 1-tap kernel reading a bf16 tensor (the FFN hidden state / WaveNet gate activations of the bf16 configuration)."""
+@pytest.mark.parametrize("compute", [capi.COMPUTE_BF16, capi.COMPUTE_F16])
+def test_conv1d_rows_kernel_bf16_input(gpu, cpu, cin, cout, mode, lengths, pre, compute, monkeypatch):
+    """The LDS-free 1-tap kernel reading a 16-bit tensor (the FFN hidden state / WaveNet gate activations of the bf16 / fp16 configurations)."""
     monkeypatch.setenv("TOUCAN_GEMM_ROWS_BF16", "1")
     w = rnd(cout, cin, 1, seed=1, scale=1.0 / np.sqrt(cin)).numpy()
     b = rnd(cout, seed=2, scale=0.1).numpy()
@@ -403,10 +418,10 @@ def test_conv1d_rows_kernel_bf16_input(gpu, cpu, cin, cout, mode, lengths, pre, 
 
     def run(ops, to):
         rag = Ragged(lengths, ops.device, align=2)
-        cw = packing.pack_conv(w, b, ops.device, mode=mode, bf16=True)
-        x = to(rnd(rag.total_rows, cin, seed=3)).to(torch.bfloat16)
+        cw = packing.pack_conv(w, b, ops.device, mode=mode, bf16=PACK16[compute])
+        x = to(rnd(rag.total_rows, cin, seed=3)).to(DT16[compute])
         y = to(rnd(rag.total_rows, co, seed=4))
-        ops.conv(cw, x, y, rag, pre=pre, pre_slope=0.1, res=to(rnd(rag.total_rows, co, seed=5)), compute=capi.COMPUTE_BF16)
+        ops.conv(cw, x, y, rag, pre=pre, pre_slope=0.1, res=to(rnd(rag.total_rows, co, seed=5)), compute=compute)
         return y
 
     gpu.small_tile_blocks = 1 << 30
@@ -414,11 +429,11 @@ def test_conv1d_rows_kernel_bf16_input(gpu, cpu, cin, cout, mode, lengths, pre, 
         g, c = both(gpu, cpu, run)
     finally:
         gpu.small_tile_blocks = 1536
-    close(g, c, 2e-2)
+    close(g, c, TOL[compute])
 
 
 @pytest.mark.parametrize("lengths", [[1000, 9, 257], [250], [251, 1, 2, 499]])
-@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("store", [torch.float32, torch.bfloat16, torch.float16])
 def test_conv_post_snake(gpu, cpu, lengths, store):
     """activation_post (anti-aliased snake) + output conv + tanh fused (BigVGAN's last two ops) vs the fp64 emulator."""
     c = 32

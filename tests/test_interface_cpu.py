@@ -64,6 +64,17 @@ def test_missing_checkpoint_and_unsupported_paths_fail_loudly(monkeypatch, model
     assert tts.default_utterance_embedding.shape == (64,)
 
 
+def test_default_cpu_device_is_refused_by_the_real_library(monkeypatch, models_dir):
+    """The reference's default device="cpu" cannot be served (there is no CPU path): a clear error, not a GPU memory fault."""
+    from ims_toucan_prosody_variance_amd import capi, engine
+    monkeypatch.setattr(capi, "_LIB", None)  # the real libtoucan_hip.so (loads without a GPU)
+    monkeypatch.setattr(interface, "MODELS_DIR", models_dir)
+    with pytest.raises(capi.ToucanHipError, match="no CPU path"):
+        engine.Ops("cpu")
+    with pytest.raises(capi.ToucanHipError, match="device='cuda'"):
+        interface.ToucanTTSInterface(tts_model_path="Meta")
+
+
 def test_read_to_file_silence_layout_and_compat_mode(tts, tmp_path):
     torch.manual_seed(0)
     out = tmp_path / "a.wav"
