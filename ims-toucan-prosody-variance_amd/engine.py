@@ -643,6 +643,25 @@ class AcousticEngine:
         out["energy"] = [en[b0:b0 + n] for b0, n in zip(rag_p.begins, rag_p.lengths)]
         return out
 
+    @torch.inference_mode()
+    def predict_frame_counts(self, texts, utt_embs, lang_ids=None, pitch=None, energy=None, duration_scaling_factor=1.0,
+                             pitch_variance_scale=1.0, energy_variance_scale=1.0, pause_duration_scaling_factor=1.0):
+        """Stage A alone (encoder, predictors, control: InferenceToucanTTS.py:206-227): mel frames each utterance will have.
+        Used to balance a multi-GPU deal by vocoder work before anything expensive runs (distributed.py)."""
+        dev = self.device
+        Ls = [int(t.shape[0]) for t in texts]
+        rag_p, rag_b = Ragged.cached(Ls, dev), Ragged.cached([len(texts)], dev)
+        text = torch.cat([t.reshape(-1, 62).to(torch.float32) for t in texts], dim=0).to(dev).contiguous()
+        emb = utt_embs.to(dev, torch.float32).reshape(len(texts), 64).contiguous()
+        cat = lambda lst: None if lst is None else torch.cat([torch.as_tensor(v).reshape(-1).to(torch.float32) for v in lst]).to(dev).contiguous()
+        lang_idx = None
+        if self.multilingual and lang_ids is not None:
+            lang_idx = torch.tensor([int(i) for i in lang_ids], dtype=torch.int32).to(dev)
+        scales = (float(duration_scaling_factor), float(pitch_variance_scale), float(energy_variance_scale), float(pause_duration_scaling_factor))
+        _, _, _, d = self._stage_a(text, emb, lang_idx, cat(pitch), cat(energy), None, rag_p, rag_b, scales)
+        d_host = d.cpu().numpy()
+        return [int(d_host[b0:b0 + n].sum()) or n for b0, n in zip(rag_p.begins, rag_p.lengths)]
+
     def _postflow(self, cat, rag_f, z_sq, taps):
         """Glow.forward(infer=True) + _forward(reverse=True): Glow.py:342-391.  z_sq: the noise in squeezed layout [RS,160]."""
         ops, dev = self.ops, self.device

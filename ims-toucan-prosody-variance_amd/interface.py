@@ -14,7 +14,6 @@ script written against the reference (run_text_to_file_reader.py:8-16) works unc
 What is NOT here (outside the hot path, unavailable offline): grapheme-to-phoneme conversion (espeak-ng),
 the GST style-embedding network behind ``set_utterance_embedding(path)``, plotting.  These raise explicit errors.
 """
-import itertools
 import os
 import wave as _wave
 
@@ -29,17 +28,17 @@ MODELS_DIR = os.environ.get("TOUCAN_MODELS_DIR", "Models/")  # Utility/storage_c
 
 
 def float2pcm(sig, dtype="int16"):
-    """Utility/utils.py:20-33."""
-    sig = np.asarray(sig)
+    """Float waveform in [-1, 1) -> integer PCM the way the reference's writer does it (Utility/utils.py:20-33): scale by half the
+    integer range around the type's mid point, saturate, and let the integer cast drop the fraction (no rounding step)."""
+    sig, dt = np.asarray(sig), np.dtype(dtype)
     if sig.dtype.kind != "f":
         raise TypeError("'sig' must be a float array")
-    dtype = np.dtype(dtype)
-    if dtype.kind not in "iu":
+    if dt.kind not in "iu":
         raise TypeError("'dtype' must be an integer type")
-    i = np.iinfo(dtype)
-    abs_max = 2 ** (i.bits - 1)
-    offset = i.min + abs_max
-    return (sig * abs_max + offset).clip(i.min, i.max).astype(dtype)
+    lo, hi = int(np.iinfo(dt).min), int(np.iinfo(dt).max)
+    half_range = float(1 << (8 * dt.itemsize - 1))
+    mid = lo + half_range  # 0 for signed types, the centre of the range for unsigned ones
+    return np.clip(sig * half_range + mid, lo, hi).astype(dt)
 
 
 def write_wav(path, data, samplerate):
@@ -104,12 +103,14 @@ class ToucanTTSInterface(torch.nn.Module):
         sd = _to_numpy_sd(checkpoint["model"])
         # variant detection: the reference retries load_state_dict (:55-63); the schema tells us directly
         self.use_lang_id = "encoder.language_embedding.weight" in sd
-        self.phone2mel = engine.AcousticEngine(sd, device)
+        # precision of the MFMA GEMMs: fp32 (exact-parity default), or TOUCAN_PRECISION=bf16 / f16 (BASELINE.json configs[2] / [4])
+        precision = os.environ.get("TOUCAN_PRECISION", "f32")
+        self.phone2mel = engine.AcousticEngine(sd, device, precision=precision)
 
         self.embedding_model_path = embedding_model_path  # GST network: not on the hot path (see module docstring)
 
         voc = _load_checkpoint(vocoder_model_path)
-        self.mel2wav = engine.VocoderEngine(_to_numpy_sd(voc["generator"]), "hifigan" if faster_vocoder else "bigvgan", device)
+        self.mel2wav = engine.VocoderEngine(_to_numpy_sd(voc["generator"]), "hifigan" if faster_vocoder else "bigvgan", device, precision=precision)
 
         self.default_utterance_embedding = checkpoint["default_emb"].to(self.device)
         self.lang_id = get_language_id_tensor(language) if self.use_lang_id else None
@@ -163,20 +164,32 @@ class ToucanTTSInterface(torch.nn.Module):
                                     pause_duration_scaling_factor=pause_duration_scaling_factor)
         return wavs[0]
 
-    def _synthesize(self, phones, embs, langs, z_noise=None, **kw):
+    def _synthesize_packed(self, phones, embs, langs, z_noise=None, **kw):
+        """One ragged batch through both engines.  Returns (packed waveform, [(first sample, sample count)] per utterance)."""
         emb = torch.stack([e.reshape(-1).to(torch.float32).cpu() for e in embs])
         lang_ids = None if any(l is None for l in langs) else langs
         out = self.phone2mel.forward(phones, emb, lang_ids, z_noise=z_noise, **kw)
         wav, rag = self.mel2wav.forward(out["mel_packed"], out["rag_mel"])
         self.last_durations, self.last_pitch, self.last_energy = out["durations"], out["pitch"], out["energy"]
-        return [wav[b:b + n] for b, n in zip(rag.begins, rag.lengths)]
+        return wav, list(zip(rag.begins, rag.lengths))
+
+    def _synthesize(self, phones, embs, langs, z_noise=None, **kw):
+        wav, spans = self._synthesize_packed(phones, embs, langs, z_noise=z_noise, **kw)
+        return [wav[b:b + n] for b, n in spans]
+
+    def predict_frame_counts(self, feats, embs, pitch=None, energy=None, **kw):
+        """Mel frames each utterance will get (stage A only) - the balancing key of the multi-GPU deal."""
+        emb = torch.stack([e.reshape(-1).to(torch.float32).cpu() for e in embs])
+        langs = None if self.lang_id is None else [self._lang()] * len(feats)
+        return self.phone2mel.predict_frame_counts(feats, emb, langs, pitch=pitch, energy=energy, **kw)
 
     def synthesize_batch(self, texts, input_is_phones=True, utterance_embeddings=None, z_noise=None, durations=None, pitch=None,
                          energy=None, duration_scaling_factor=1.0, pitch_variance_scale=1.0, energy_variance_scale=1.0,
                          pause_duration_scaling_factor=1.0, distributed=False):
         """Additive API: a ragged batch in one pass; each utterance equals the reference run on it alone.
-        texts: phoneme strings (or [L,62] feature tensors).  With ``distributed=True`` and an initialised process group the
-        utterances are dealt over the ranks by length and every rank returns all waveforms (one all-gather)."""
+        texts: phoneme strings (or [L,62] feature tensors).  durations / pitch / energy: optional per-utterance gold prosody (the
+        cloner-style call, UtteranceCloner.py:163).  With ``distributed=True`` and an initialised process group the utterances are
+        dealt over the ranks by frame count and every rank returns all waveforms (distributed.py)."""
         feats = [t if torch.is_tensor(t) else self.text2phone.string_to_tensor(t, input_phonemes=input_is_phones) for t in texts]
         embs = utterance_embeddings if utterance_embeddings is not None else [self.default_utterance_embedding] * len(feats)
         kw = dict(duration_scaling_factor=duration_scaling_factor, pitch_variance_scale=pitch_variance_scale,
@@ -187,6 +200,20 @@ class ToucanTTSInterface(torch.nn.Module):
                                         energy=energy, **kw)
         from . import distributed as dd
         return dd.synthesize_sharded(self, feats, embs, z_noise, durations, pitch, energy, kw)
+
+    def synthesize_ensemble(self, text, utterance_embeddings, durations=None, pitch=None, energy=None, input_is_phones=True, z_noise=None):
+        """Several voices speaking one text with the same prosody, averaged (UtteranceCloner.py:166-194's ensemble) - as ONE batch
+        over the voices instead of a loop that swaps the default embedding.  Without gold durations the voices may predict
+        different lengths; the mean is then taken over the common prefix."""
+        n = len(utterance_embeddings)
+        rep = lambda v: None if v is None else [v] * n
+        waves = self.synthesize_batch([text] * n, input_is_phones=input_is_phones, utterance_embeddings=list(utterance_embeddings),
+                                      durations=rep(durations), pitch=rep(pitch), energy=rep(energy), z_noise=z_noise)
+        m = min(w.numel() for w in waves)
+        return torch.stack([w[:m] for w in waves]).mean(dim=0)
+
+    SILENCE_SAMPLES = 10600   # between sentences in read_to_file (ToucanTTSInterface.py:267)
+    MAX_FILE_BATCH = 32       # sentences synthesised per ragged batch by read_to_file
 
     def read_to_file(self,
                      text_list,
@@ -200,48 +227,61 @@ class ToucanTTSInterface(torch.nn.Module):
                      energy_list=None,
                      increased_compatibility_mode=False,
                      input_is_phones=False):
-        if not dur_list:
-            dur_list = []
-        if not pitch_list:
-            pitch_list = []
-        if not energy_list:
-            energy_list = []
-        silence = torch.zeros([10600])
-        wav = silence.clone()
-        for (text, durations, pitch, energy) in itertools.zip_longest(text_list, dur_list, pitch_list, energy_list):
-            if text.strip() != "":
-                if not silent:
-                    print("Now synthesizing: {}".format(text))
-                spoken_sentence = self(text,
-                                       durations=durations.to(self.device) if durations is not None else None,
-                                       pitch=pitch.to(self.device) if pitch is not None else None,
-                                       energy=energy.to(self.device) if energy is not None else None,
-                                       duration_scaling_factor=duration_scaling_factor,
-                                       pitch_variance_scale=pitch_variance_scale,
-                                       energy_variance_scale=energy_variance_scale,
-                                       input_is_phones=input_is_phones).cpu()
-                wav = torch.cat((wav, spoken_sentence, silence), 0)
-        if increased_compatibility_mode:
-            doubled = np.repeat(wav.numpy(), 2)  # 24 kHz -> 48 kHz by sample doubling (:282)
-            write_wav(file_location, float2pcm(doubled), 48000)
+        """Same result as the reference's sentence loop (:231-285: silence, sentence, silence, ... with blank strings skipped,
+        24 kHz float file or sample-doubled 48 kHz PCM16), but the sentences go through the engines as ragged batches of up to
+        MAX_FILE_BATCH utterances and the file is assembled once on the host."""
+        n = len(text_list)
+        column = lambda lst: list(lst) + [None] * (n - len(lst)) if lst else [None] * n
+        durs, pits, enes = column(dur_list), column(pitch_list), column(energy_list)
+        spoken = [i for i, t in enumerate(text_list) if t.strip() != ""]
+        pieces = {}
+        for lo in range(0, len(spoken), self.MAX_FILE_BATCH):
+            chunk = spoken[lo:lo + self.MAX_FILE_BATCH]
+            if not silent:
+                for i in chunk:
+                    print("Now synthesizing: {}".format(text_list[i]))
+            # gold prosody is per sentence and optional per sentence: sentences that share the same set of gold quantities
+            # form one batch (the engines take a quantity either for every utterance of a batch or for none)
+            groups = {}
+            for i in chunk:
+                groups.setdefault((durs[i] is not None, pits[i] is not None, enes[i] is not None), []).append(i)
+            for (has_d, has_p, has_e), idx in groups.items():
+                waves = self.synthesize_batch([text_list[i] for i in idx], input_is_phones=input_is_phones,
+                                              durations=[durs[i] for i in idx] if has_d else None,
+                                              pitch=[pits[i] for i in idx] if has_p else None,
+                                              energy=[enes[i] for i in idx] if has_e else None,
+                                              duration_scaling_factor=duration_scaling_factor, pitch_variance_scale=pitch_variance_scale,
+                                              energy_variance_scale=energy_variance_scale)
+                for i, w in zip(idx, waves):
+                    pieces[i] = w.cpu().numpy()
+        gap = self.SILENCE_SAMPLES
+        total = gap + sum(pieces[i].shape[0] + gap for i in spoken)
+        audio = np.zeros(total, dtype=np.float32)
+        at = gap
+        for i in spoken:
+            audio[at:at + pieces[i].shape[0]] = pieces[i]
+            at += pieces[i].shape[0] + gap
+        if increased_compatibility_mode:  # 24 kHz is less widely supported than 48 kHz: every sample twice, 16-bit integers
+            write_wav(file_location, float2pcm(np.repeat(audio, 2)), 48000)
         else:
-            write_wav(file_location, wav.numpy(), 24000)
+            write_wav(file_location, audio, 24000)
 
     def read_aloud(self, text, view=False, duration_scaling_factor=1.0, pitch_variance_scale=1.0, energy_variance_scale=1.0,
                    blocking=False, increased_compatibility_mode=False):
-        if text.strip() == "":
+        """Synthesise and play one text through the sound card (:287-309); half a second of silence is appended."""
+        if not text.strip():
             return
         try:
             import sounddevice
         except ImportError as e:
             raise RuntimeError("read_aloud needs the sounddevice package") from e
-        wav = self(text, view, duration_scaling_factor=duration_scaling_factor, pitch_variance_scale=pitch_variance_scale,
-                   energy_variance_scale=energy_variance_scale).cpu()
-        wav = torch.cat((wav, torch.zeros([12000])), 0).numpy()
+        speech = self(text, view, duration_scaling_factor=duration_scaling_factor, pitch_variance_scale=pitch_variance_scale,
+                      energy_variance_scale=energy_variance_scale)
+        audio = np.concatenate([speech.cpu().numpy(), np.zeros(12000, dtype=np.float32)])
         if increased_compatibility_mode:
-            sounddevice.play(float2pcm(np.repeat(wav, 2)), samplerate=48000)
+            sounddevice.play(float2pcm(np.repeat(audio, 2)), samplerate=48000)
         else:
-            sounddevice.play(wav, samplerate=24000)
+            sounddevice.play(audio, samplerate=24000)
         if blocking:
             sounddevice.wait()
 

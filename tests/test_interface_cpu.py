@@ -83,7 +83,9 @@ def test_read_to_file_silence_layout_and_compat_mode(tts, tmp_path):
         assert f.getframerate() == 24000 and f.getsampwidth() == 2
         n = f.getnframes()
         data = np.frombuffer(f.readframes(n), dtype="<i2")
-    frames = int(sum(int(d.sum()) for d in tts.last_durations))
+    assert len(tts.last_durations) == 2  # both sentences went through the engines as one ragged batch
+    frames = int(tts.last_durations[0].sum())
+    assert frames == int(tts.last_durations[1].sum())
     per = 384 * (frames - frames % 2)
     assert n == 10600 + 2 * (per + 10600)  # silence, sentence, silence, sentence, silence; blank string skipped
     assert not data[:10600].any() and not data[-10600:].any()
@@ -94,8 +96,32 @@ def test_read_to_file_silence_layout_and_compat_mode(tts, tmp_path):
 
 
 def test_float2pcm_matches_reference_formula():
-    x = np.array([-1.0, -0.5, 0.0, 0.5, 0.99997, 1.0], dtype=np.float32)
-    assert interface.float2pcm(x).tolist() == [-32768, -16384, 0, 16384, 32767, 32767]
+    x = np.array([-1.0, -0.5, 0.0, 0.5, 0.99997, 1.0, -0.99999, 3.0e-5, -3.0e-5, 2.0, -2.0], dtype=np.float32)
+    assert interface.float2pcm(x).tolist() == [-32768, -16384, 0, 16384, 32767, 32767, -32767, 0, 0, 32767, -32768]  # truncation, saturation
+    assert interface.float2pcm(np.array([-1.0, 0.0, 1.0]), "uint8").tolist() == [0, 128, 255]
+    with pytest.raises(TypeError):
+        interface.float2pcm(np.array([1, 2]))
+
+
+def test_read_to_file_with_per_sentence_gold_prosody_and_ensemble(tts, tmp_path):
+    """dur_list / pitch_list / energy_list shorter than text_list (the reference's zip_longest semantics): sentences with and
+    without gold values are grouped into separate batches; the cloner-style ensemble averages several voices in one batch."""
+    torch.manual_seed(0)
+    L = int(tts.text2phone.string_to_tensor(PHONES_B, input_phonemes=True).shape[0])
+    gold = torch.full((L,), 3, dtype=torch.long)
+    out = tmp_path / "g.wav"
+    tts.read_to_file([PHONES_B, PHONES_B], str(out), silent=True, input_is_phones=True, dur_list=[gold])
+    with wave.open(str(out)) as f:
+        n = f.getnframes()
+    feats = tts.text2phone.string_to_tensor(PHONES_B, input_phonemes=True)
+    gold_frames = int(gold[feats[:, 21] != 1].sum())
+    pred_frames = int(tts.last_durations[0].sum())  # the last batch was the sentence without gold durations
+    assert n == 10600 + (384 * (gold_frames - gold_frames % 2) + 10600) + (384 * (pred_frames - pred_frames % 2) + 10600)
+    embs = [torch.randn(64, generator=torch.Generator().manual_seed(s)) for s in (1, 2, 3)]
+    z = [torch.randn(80, 200, generator=torch.Generator().manual_seed(9)) * 0.8] * 3
+    mean = tts.synthesize_ensemble(PHONES_B, embs, durations=gold, z_noise=z)
+    singles = tts.synthesize_batch([PHONES_B] * 3, utterance_embeddings=embs, durations=[gold] * 3, z_noise=z)
+    assert torch.allclose(mean, torch.stack(singles).mean(0), atol=1e-6)
 
 
 def test_batch_equals_one_by_one(tts):
@@ -126,26 +152,35 @@ def _rank_main(rank, world, port, models_dir, q):
     tts = interface.ToucanTTSInterface(device="cpu", tts_model_path="Meta", faster_vocoder=True)
     texts = [PHONES_A, PHONES_B, "~ˈa~#"]
     z = [torch.randn(80, 400, generator=torch.Generator().manual_seed(i)) * 0.8 for i in range(3)]
-    waves = tts.synthesize_batch(texts, z_noise=z, distributed=True)
+    kw = {}
+    if world == 4:  # ragged counts: 3 utterances on 4 ranks leave one shard EMPTY; gold durations on this leg (host-side cost key)
+        L = [int(tts.text2phone.string_to_tensor(t, input_phonemes=True).shape[0]) for t in texts]
+        kw["durations"] = [torch.full((n,), 2 + i, dtype=torch.long) for i, n in enumerate(L)]
+    waves = tts.synthesize_batch(texts, z_noise=z, distributed=True, **kw)
     if rank == 0:
-        single = tts.synthesize_batch(texts, z_noise=z)
+        single = tts.synthesize_batch(texts, z_noise=z, **kw)
         q.put([float((a - b).abs().max()) if a.shape == b.shape else 1e9 for a, b in zip(waves, single)])
     else:
         q.put([w.numel() for w in waves])
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_sharding_matches_single_process(models_dir):
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharding_matches_single_process(models_dir, world):
+    """world 2: predicted durations (stage A + frame-count all-gather + re-deal by frames); world 4: gold durations, ragged
+    shard sizes with one empty shard.  Sharded == single process, bit for bit, on every rank's copy."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, models_dir, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, models_dir, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     errs = [r for r in res if isinstance(r[0], float)][0]
     assert max(errs) == 0.0, errs  # same kernels, same per-utterance arithmetic -> identical
+    sizes = [r for r in res if not isinstance(r[0], float)]
+    assert all(s == sizes[0] for s in sizes) and len(sizes[0]) == 3  # every rank holds every waveform
