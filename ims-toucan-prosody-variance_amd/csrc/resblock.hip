@@ -17,8 +17,11 @@
 //   * epilogue: + bias2, alpha, + res_scale * x (re-read from global, L2-resident), optional accumulate, fp32 store.
 // Rows outside the utterance are zero after each activation (the reference zero-pads every conv per utterance).
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
+#include <cstdlib>
+
 #include "common.h"
 #include "snake.h"
+#include "snake_mfma.h"
 
 namespace tts {
 
@@ -43,6 +46,8 @@ struct RbCfg {
   static constexpr int NCH1 = (C == 32 || C == 256) ? 3 : 5;
   static constexpr int GR1 = 8 * NCH1;
   static constexpr int win_alloc(int h1) { return (M1 + 2 * h1 + GR1 - 1) / GR1 * GR1; }
+  // matrix-core snake: 6 raw rows, the window rounded up to whole 16-row tiles, 6 raw rows
+  static constexpr int img_rows(int h1) { return 6 + (M1 + 2 * h1 + 15) / 16 * 16 + 6; }
   // The streamed snake stores come in two equivalent forms; which one the compiler schedules well differs per instantiation
   // (measured inside one run: C = 32 gains 10 % from the unguarded form; C = 64 and 256 lose 10 % to it - it hoists every
   // LDS address and spills): unguarded = no row bound (the window is padded to whole items) and one unsigned range compare.
@@ -96,7 +101,9 @@ struct RbSlab {
 // waves per SIMD the register allocation must leave room for: 2 / 2 / 1 / 1 workgroups per CU (C = 32 / 64 / 128 / 256)
 // IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
 // F16: the 16-bit element format everywhere in the kernel (LDS tiles, weights, 16-bit x / y) is IEEE fp16 instead of bf16
-template <int C, bool IOB, bool F16>
+// MFIR: the two anti-aliased snakes run their FIR filters on the matrix cores (snake_mfma.h) instead of the register-streamed
+//       VALU form; the activation window then carries 6 raw rows in front and behind (the filters' reach) and is transformed in place
+template <int C, bool IOB, bool F16, bool MFIR>
 // (C = 32: with the prefetching snake two spill-free workgroups per CU beat three at the 80-register cap by ~10 %)
 __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d) {
   constexpr int RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
@@ -121,11 +128,15 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 
   const int h1 = (d.taps - 1) / 2 * d.dil, h2 = (d.taps - 1) / 2;
   const int win_rows = RB_M1 + 2 * h1;
+  static_assert(!MFIR || (C <= 128 && KC == C), "the matrix-core snake needs whole-C slabs (one window pitch for xa and t1)");
+  constexpr int PADR = MFIR ? 6 : 0;  // raw rows in front of / behind the window (reach of the up-sampler + decimator)
   // xa (act1(x) window) is dead once conv1 has finished, so t1 (conv1 output) overlays it
-  const size_t xa_elems = ((size_t)RbCfg<C>::win_alloc(h1) * XP + 7) & ~(size_t)7, t1_elems = (size_t)RB_M1 * TP;
-  unsigned short* xa = reinterpret_cast<unsigned short*>(lds_raw);          // [win_alloc][XP]
+  const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
+  const size_t xa_elems = ((size_t)img_rows * XP + 7) & ~(size_t)7, t1_elems = (size_t)(RB_M1 + 2 * PADR) * TP;
+  unsigned short* img = reinterpret_cast<unsigned short*>(lds_raw);         // [img_rows][XP]: PADR raw rows, the window, PADR raw rows
+  unsigned short* xa = img + PADR * XP;                                     // [win_alloc][XP]
   unsigned short* t1 = xa;                                                  // [M1][TP]
-  unsigned short* ws = xa + (xa_elems > t1_elems ? xa_elems : t1_elems);    // [2][SLAB]
+  unsigned short* ws = img + (xa_elems > t1_elems ? xa_elems : t1_elems);   // [2][SLAB]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lk = lane >> 5;
   const int T = tile.seq_end - tile.seq_begin;
@@ -174,7 +185,70 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     if (ch > 0) __syncthreads();
     // window row j <-> local frame l0 - LEAD - h1 + j
     const int wbase = l0 - RB_LEAD - h1;
-    if (snake) {
+    if (MFIR && snake) {
+      if constexpr (MFIR) {
+        // raw x (as fp16, zero outside the utterance) into the whole image, then both FIR filters of act1 on the matrix cores, in place
+        constexpr int Q8 = C / 8, PER = 4;
+        const int total = img_rows * Q8;
+        for (int base = tid; base < total; base += RB_THREADS * PER) {
+          uint4 v[PER], v2[PER];
+#pragma unroll
+          for (int p = 0; p < PER; ++p) {
+            int e = base + p * RB_THREADS;
+            e = e < total ? e : total - 1;
+            const int r = e / Q8, c8 = (e % Q8) * 8;
+            const int t = wbase - PADR + r;
+            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+            if constexpr (IOB) {
+              v[p] = *reinterpret_cast<const uint4*>(xh + (size_t)(tile.seq_begin + tc) * d.ldx + c8);
+            } else {
+              v[p] = *reinterpret_cast<const uint4*>(d.x + (size_t)(tile.seq_begin + tc) * d.ldx + c8);
+              v2[p] = *reinterpret_cast<const uint4*>(d.x + (size_t)(tile.seq_begin + tc) * d.ldx + c8 + 4);
+            }
+            if (t < 0 || t >= T) { v[p] = make_uint4(0, 0, 0, 0); v2[p] = make_uint4(0, 0, 0, 0); }
+          }
+#pragma unroll
+          for (int p = 0; p < PER; ++p) {
+            const int e = base + p * RB_THREADS;
+            if (e >= total) continue;
+            const int r = e / Q8, c8 = (e % Q8) * 8;
+            uint4 o;
+            if constexpr (IOB && F16) {
+              o = v[p];
+            } else if constexpr (IOB) {  // bf16 -> fp16 (exact for |x| in fp16's range)
+              const unsigned int w4[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+              unsigned int o4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o4[q] = pack16<true>(bf16_to_f32(w4[q] & 0xFFFF), bf16_to_f32(w4[q] >> 16));
+              o = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            } else {
+              auto f = [](unsigned int b) { return __builtin_bit_cast(float, b); };
+              o = make_uint4(pack16<true>(f(v[p].x), f(v[p].y)), pack16<true>(f(v[p].z), f(v[p].w)),
+                             pack16<true>(f(v2[p].x), f(v2[p].y)), pack16<true>(f(v2[p].z), f(v2[p].w)));
+            }
+            *reinterpret_cast<uint4*>(img + r * XP + c8) = o;
+          }
+        }
+        constexpr int CB = C / 16, SEG = 8 / CB;
+        const int cb = wave % CB, seg = wave / CB;
+        const int tiles_total = (win_rows + 15) / 16;
+        const int t_lo = seg * tiles_total / SEG, t_hi = (seg + 1) * tiles_total / SEG;
+        const int chn = cb * 16 + (lane & 15);
+        SnakeFir fir;
+        fir.img = img; fir.pitch = XP; fir.last_row = img_rows - 1;
+        fir.frame0 = wbase - PADR; fir.T = T; fir.ch0 = cb * 16;
+        fir.row_begin = 16 * t_lo; fir.n_tiles = t_hi - t_lo;
+        fir.er = expf(d.alpha1[chn]) * 0.15915494309189535f;
+        fir.inv_b = 1.0f / (expf(d.beta1[chn]) + 1e-9f);
+        __syncthreads();
+        FirTaps ft;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
+        fir.begin(ft, lane);
+        __syncthreads();
+        fir.template sweep<F16>(ft, lane);
+      }
+    } else if (snake) {
       // anti-aliased snake while staging: item = (8*NCH1 window rows, channel), streamed so that only the first chunk pays the halo
       constexpr int NCH1 = RbCfg<C>::NCH1, GR = RbCfg<C>::GR1;
       const int items = ((win_rows + GR - 1) / GR) * KC;
@@ -294,12 +368,32 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       float v = acc[j][r] + b1;
       if (!snake) v = v > 0.f ? v : v * d.slope;
       if (t < 0 || t >= T) v = 0.0f;  // act2 output outside the utterance is conv2's zero padding
-      t1[i * TP + n] = to16<F16>(v);
+      t1[i * TP + n] = (MFIR && snake) ? to16<true>(v) : to16<F16>(v);  // (the matrix-core snake reads fp16)
       acc[j][r] = 0.0f;
     }
   }
   __syncthreads();
-  if (snake) {
+  if (MFIR && snake) {
+    if constexpr (MFIR) {
+      // act2 in place on t1 (rows [0, M1) of the window; the 6 rows on either side only feed outputs conv2 never reads)
+      constexpr int CB = C / 16, SEG = 8 / CB;
+      const int cb = wave % CB, seg = wave / CB;
+      constexpr int tiles_total = RB_M1 / 16;
+      const int chn = cb * 16 + (lane & 15);
+      SnakeFir fir;
+      fir.img = img; fir.pitch = TP; fir.last_row = RB_M1 + 2 * PADR - 1;
+      fir.frame0 = l0 - RB_LEAD - PADR; fir.T = T; fir.ch0 = cb * 16;
+      fir.row_begin = 16 * (seg * tiles_total / SEG); fir.n_tiles = tiles_total / SEG;
+      fir.er = expf(d.alpha2[chn]) * 0.15915494309189535f;
+      fir.inv_b = 1.0f / (expf(d.beta2[chn]) + 1e-9f);
+      FirTaps ft;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
+      fir.begin(ft, lane);
+      __syncthreads();
+      fir.template sweep<F16>(ft, lane);
+    }
+  } else if (snake) {
     const int base = l0 - RB_LEAD;  // local frame of t1 row 0
     if constexpr (C == RB_THREADS) {
       // C = 256: one thread per channel streams down all M1 rows.  The stream reads every raw row (up to 13 rows ahead)
@@ -438,16 +532,17 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #undef load_slab
 #undef store_slab
 
-template <int C, bool IOB, bool F16>
+template <int C, bool IOB, bool F16, bool MFIR>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   constexpr int KC = RbCfg<C>::KC, RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   const int h1 = (d.taps - 1) / 2 * d.dil;
-  const size_t xa = (((size_t)RbCfg<C>::win_alloc(h1) * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)RB_M1 * (C + 8);
+  const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
+  const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
   const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
   size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2;
   if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
-  auto k = resblock_step_kernel<C, IOB, F16>;
+  auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
   if (lds > 64 * 1024 && raise_lds_limit(reinterpret_cast<const void*>(k), lds_raised) != hipSuccess) {
     set_error("resblock_step: raising the dynamic LDS limit failed");
@@ -472,12 +567,14 @@ int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(!d.io_bf16 || ((d.ldx & 7) == 0 && (d.ldy & 7) == 0 && ((uintptr_t)d.y & 15) == 0), "resblock_step: bf16 rows must be 16-byte aligned");
   TTS_CHECK_ARG(d.compute == 1 || d.compute == 2, "resblock_step: compute must be 1 (bf16) or 2 (fp16), got %d", d.compute);
   if (d.n_tiles == 0) return TTS_OK;
-#define TTS_RB(IOB_, F16_)                                    \
-  switch (d.c) {                                              \
-    case 32: return launch_rb<32, IOB_, F16_>(d, st);         \
-    case 64: return launch_rb<64, IOB_, F16_>(d, st);         \
-    case 128: return launch_rb<128, IOB_, F16_>(d, st);       \
-    default: return launch_rb<256, IOB_, F16_>(d, st);        \
+  // C <= 128: the snakes' FIR filters on the matrix cores (TOUCAN_SNAKE_VALU=1 keeps the register-streamed VALU form for A/B runs)
+  static const bool valu_snake = std::getenv("TOUCAN_SNAKE_VALU") != nullptr;
+#define TTS_RB(IOB_, F16_)                                                                                  \
+  switch (d.c) {                                                                                            \
+    case 32: return valu_snake ? launch_rb<32, IOB_, F16_, false>(d, st) : launch_rb<32, IOB_, F16_, true>(d, st);    \
+    case 64: return valu_snake ? launch_rb<64, IOB_, F16_, false>(d, st) : launch_rb<64, IOB_, F16_, true>(d, st);    \
+    case 128: return valu_snake ? launch_rb<128, IOB_, F16_, false>(d, st) : launch_rb<128, IOB_, F16_, true>(d, st); \
+    default: return launch_rb<256, IOB_, F16_, false>(d, st);                                               \
   }
   if (d.compute == 2) {
     if (d.io_bf16) { TTS_RB(true, true) }
