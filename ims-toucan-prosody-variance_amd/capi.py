@@ -57,6 +57,7 @@ class TtsResblockDesc(C.Structure):
         ("io_bf16", _i),
         ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
         ("compute", _i),
+        ("fir_tab", _p),
     ]
 
 
@@ -72,6 +73,7 @@ PROTOTYPES = {
     "tts_conv1d": (C.c_int, [C.POINTER(TtsConvDesc), _p]),
     "tts_resblock_step": (C.c_int, [C.POINTER(TtsResblockDesc), _p]),
     "tts_resblock_tile_rows": (C.c_int, [_i]),
+    "tts_snake_fir_table": (C.c_int, [_p, _p]),
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     "tts_cln_mlp_weight_floats": (C.c_int64, [_i, _i]),

@@ -47,6 +47,7 @@ int conv_post(const float*, int, int, const float*, float, int, float, float*, c
 int gather_rows(const float*, int, const int*, float*, int, int, int, hipStream_t);
 int resblock_step(const TtsResblockDesc& d, hipStream_t st);
 int resblock_tile_rows(int c);
+int snake_fir_table(const float* filt, void* table);
 
 }  // namespace tts
 
@@ -70,6 +71,7 @@ int tts_conv1d(const TtsConvDesc* d, tts_stream_t stream) {
 }
 
 int tts_resblock_tile_rows(int32_t c) { return tts::resblock_tile_rows(c); }
+int tts_snake_fir_table(const float* filt, void* table) { return tts::snake_fir_table(filt, table); }
 
 int tts_resblock_step(const TtsResblockDesc* d, tts_stream_t stream) {
   if (!d) {

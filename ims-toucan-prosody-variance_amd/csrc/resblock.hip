@@ -18,6 +18,7 @@
 // Rows outside the utterance are zero after each activation (the reference zero-pads every conv per utterance).
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 #include "snake.h"
@@ -31,6 +32,9 @@ namespace tts {
 #endif
 #ifndef RB_C32_PREFETCH
 #define RB_C32_PREFETCH 1   // one-chunk-ahead input prefetch in the C = 32 snake (costs 8 registers)
+#endif
+#ifndef RB_C64_TPS
+#define RB_C64_TPS 1        // taps per weight slab at C = 64 (tuning knob)
 #endif
 constexpr int RB_LEAD = 16;
 // C <= 128: conv1 on M1 = 256 rows (8 waves), 224 output rows, whole-C weight slabs.
@@ -47,7 +51,8 @@ struct RbCfg {
   static constexpr int GR1 = 8 * NCH1;
   static constexpr int win_alloc(int h1) { return (M1 + 2 * h1 + GR1 - 1) / GR1 * GR1; }
   // matrix-core snake: 6 raw rows, the window rounded up to whole 16-row tiles, 6 raw rows
-  static constexpr int img_rows(int h1) { return 6 + (M1 + 2 * h1 + 15) / 16 * 16 + 6; }
+  // (+ 26: the last up-sampler window of a run reaches 31 rows past the run's end; those rows only meet zero taps)
+  static constexpr int img_rows(int h1) { return (M1 + 2 * h1 + 15) / 16 * 16 + 32; }
   // The streamed snake stores come in two equivalent forms; which one the compiler schedules well differs per instantiation
   // (measured inside one run: C = 32 gains 10 % from the unguarded form; C = 64 and 256 lose 10 % to it - it hoists every
   // LDS address and spills): unguarded = no row bound (the window is padded to whole items) and one unsigned range compare.
@@ -55,7 +60,7 @@ struct RbCfg {
   // taps per weight slab: a slab step costs one workgroup barrier, and at C = 32 / 64 a single tap is only 2 / 8 MFMAs per
   // wave: C = 32 moves a whole conv per step (<= 22 KB; lrelu step -8..-22 %, snake step -3..-11 % measured).  Two taps per
   // step at C = 64 measured neutral and doubled the scalar-register spills, so it keeps one
-  static constexpr int TPS = C == 32 ? 11 : 1;
+  static constexpr int TPS = C == 32 ? 11 : (C == 64 ? RB_C64_TPS : 1);
 };
 
 // register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
@@ -197,7 +202,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
             int e = base + p * RB_THREADS;
             e = e < total ? e : total - 1;
             const int r = e / Q8, c8 = (e % Q8) * 8;
-            const int t = wbase - PADR + r;
+            int t = wbase - PADR + r;
+            if (r >= win_rows + 2 * PADR) t = -1;  // surplus rows behind the window: zeros
             const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
             if constexpr (IOB) {
               v[p] = *reinterpret_cast<const uint4*>(xh + (size_t)(tile.seq_begin + tc) * d.ldx + c8);
@@ -235,18 +241,20 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         const int t_lo = seg * tiles_total / SEG, t_hi = (seg + 1) * tiles_total / SEG;
         const int chn = cb * 16 + (lane & 15);
         SnakeFir fir;
-        fir.img = img; fir.pitch = XP; fir.last_row = img_rows - 1;
+        fir.img = img; fir.pitch = XP;
         fir.frame0 = wbase - PADR; fir.T = T; fir.ch0 = cb * 16;
-        fir.row_begin = 16 * t_lo; fir.n_tiles = t_hi - t_lo;
+        fir.row_begin = __builtin_amdgcn_readfirstlane(16 * t_lo); fir.n_tiles = __builtin_amdgcn_readfirstlane(t_hi - t_lo);
         fir.er = expf(d.alpha1[chn]) * 0.15915494309189535f;
         fir.inv_b = 1.0f / (expf(d.beta1[chn]) + 1e-9f);
         __syncthreads();
         FirTaps ft;
 #pragma unroll
         for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
-        fir.begin(ft, lane);
+#ifndef RB_DIAG_NO_SWEEP1  // (timing diagnostics only: tools/build_variant.sh NAME -DRB_DIAG_NO_SWEEP1)
+        fir.begin(d.fir_tab, lane);
         __syncthreads();
         fir.template sweep<F16>(ft, lane);
+#endif
       }
     } else if (snake) {
       // anti-aliased snake while staging: item = (8*NCH1 window rows, channel), streamed so that only the first chunk pays the halo
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-            acc[j] = mfma16<F16>(a, b, acc[j]);
+            acc[j] = mfma16<F16>(b, a, acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
           }
         }
       }
@@ -357,19 +365,32 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   // ------------------------------------------------------------------ t1 = conv1 + bias (LeakyReLU applied here), bf16 in LDS
   // t1 row i <-> local frame l0 - LEAD + i
   __syncthreads();  // every wave is done reading xa (t1 overlays it)
+  {
+    // Both convs run transposed (weights as the A operand): a lane owns ONE frame and its accumulator registers hold four
+    // consecutive output channels per group of four - a 16-bit quadruple is one 8-byte LDS store, and "outside the utterance"
+    // is one predicate per lane instead of one per register.
+    const int i = wave * 32 + lrow;      // t1 row of this lane
+    const int t = l0 - RB_LEAD + i;
+    const bool live = t >= 0 && t < T;   // act2 output outside the utterance is conv2's zero padding
+    const bool as_f16 = F16 || (MFIR && snake);  // (the matrix-core snake reads fp16)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = j * 32 + lrow;
-    const float b1 = d.b1[n];
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      const int t = l0 - RB_LEAD + i;
-      float v = acc[j][r] + b1;
-      if (!snake) v = v > 0.f ? v : v * d.slope;
-      if (t < 0 || t >= T) v = 0.0f;  // act2 output outside the utterance is conv2's zero padding
-      t1[i * TP + n] = (MFIR && snake) ? to16<true>(v) : to16<F16>(v);  // (the matrix-core snake reads fp16)
-      acc[j][r] = 0.0f;
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n0 = j * 32 + 8 * rq + 4 * lk;
+        const float4 bb = *reinterpret_cast<const float4*>(d.b1 + n0);
+        float v[4] = {acc[j][4 * rq] + bb.x, acc[j][4 * rq + 1] + bb.y, acc[j][4 * rq + 2] + bb.z, acc[j][4 * rq + 3] + bb.w};
+        if (!snake) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], v[q] * d.slope);  // LeakyReLU (0 < slope < 1)
+        }
+        uint2 o = as_f16 ? make_uint2(pack16<true>(v[0], v[1]), pack16<true>(v[2], v[3]))
+                         : make_uint2(pack16<false>(v[0], v[1]), pack16<false>(v[2], v[3]));
+        if (!live) o = make_uint2(0, 0);
+        *reinterpret_cast<uint2*>(t1 + i * TP + n0) = o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][4 * rq + q] = 0.0f;
+      }
     }
   }
   __syncthreads();
@@ -381,17 +402,19 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       constexpr int tiles_total = RB_M1 / 16;
       const int chn = cb * 16 + (lane & 15);
       SnakeFir fir;
-      fir.img = img; fir.pitch = TP; fir.last_row = RB_M1 + 2 * PADR - 1;
+      fir.img = img; fir.pitch = TP;  // (rows past M1 + 12 still hold act1(x): finite)
       fir.frame0 = l0 - RB_LEAD - PADR; fir.T = T; fir.ch0 = cb * 16;
-      fir.row_begin = 16 * (seg * tiles_total / SEG); fir.n_tiles = tiles_total / SEG;
+      fir.row_begin = __builtin_amdgcn_readfirstlane(16 * (seg * tiles_total / SEG)); fir.n_tiles = tiles_total / SEG;
       fir.er = expf(d.alpha2[chn]) * 0.15915494309189535f;
       fir.inv_b = 1.0f / (expf(d.beta2[chn]) + 1e-9f);
       FirTaps ft;
 #pragma unroll
       for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
-      fir.begin(ft, lane);
+#ifndef RB_DIAG_NO_SWEEP2
+      fir.begin(d.fir_tab, lane);
       __syncthreads();
       fir.template sweep<F16>(ft, lane);
+#endif
     }
   } else if (snake) {
     const int base = l0 - RB_LEAD;  // local frame of t1 row 0
@@ -463,7 +486,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
               const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-              acc[j] = mfma16<F16>(a, b, acc[j]);
+              acc[j] = mfma16<F16>(b, a, acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
             }
           }
         }
@@ -473,57 +496,54 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   }
 
   // ------------------------------------------------------------------ epilogue
-  if constexpr (IOB) {
-    // bf16 tensors: the fp32 tile alpha*(conv2 + b2) goes through LDS (it overlays xa/t1/ws, all dead now) so that the
-    // residual read and the output write are whole 16-byte row segments instead of 2-byte column accesses
-    float* ot = reinterpret_cast<float*>(lds_raw);  // [BM][C]
-    __syncthreads();                                // every wave is done reading t1 / ws
-    if (wave < RB_BM / 32) {
+  // transposed accumulators again: lane = output row, registers = groups of four consecutive channels.  Residual read, scaling,
+  // optional accumulate and the store happen in registers on 8-byte (16-bit tensors) or 16-byte (fp32) pieces of the row: no
+  // LDS round trip, no barrier.  A row's pieces are written by one wavefront within a few hundred cycles, so L2 merges them
+  // into whole lines before they reach HBM.
+  if (wave < RB_BM / 32) {
+    const int row = tile.row0 + wave * 32 + lrow;
+    if (row < tile.seq_end) {
+      unsigned short* yh = reinterpret_cast<unsigned short*>(d.y);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = j * 32 + lrow;
-        const float b2 = d.b2[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ot[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * C + n] = d.alpha * (acc[j][r] + b2);
-      }
-    }
-    __syncthreads();
-    unsigned short* yh = reinterpret_cast<unsigned short*>(d.y);
-    constexpr int Q8 = C / 8;
-    for (int e = tid; e < RB_BM * Q8; e += RB_THREADS) {
-      const int orow = e / Q8, c8 = (e % Q8) * 8;
-      const int row = tile.row0 + orow;
-      if (row >= tile.seq_end) break;
-      const uint4 xr = *reinterpret_cast<const uint4*>(xh + (size_t)row * d.ldx + c8);
-      uint4 yr = make_uint4(0, 0, 0, 0);
-      if (d.accumulate) yr = *reinterpret_cast<const uint4*>(yh + (size_t)row * d.ldy + c8);
-      const float4 o0 = *reinterpret_cast<const float4*>(ot + orow * C + c8), o1 = *reinterpret_cast<const float4*>(ot + orow * C + c8 + 4);
-      const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-      const unsigned int xw[4] = {xr.x, xr.y, xr.z, xr.w}, yw[4] = {yr.x, yr.y, yr.z, yr.w};
-      unsigned int o4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float lo = ov[2 * q] + d.res_scale * from16<F16>(xw[q] & 0xFFFF), hi2 = ov[2 * q + 1] + d.res_scale * from16<F16>(xw[q] >> 16);
-        if (d.accumulate) { lo += from16<F16>(yw[q] & 0xFFFF); hi2 += from16<F16>(yw[q] >> 16); }
-        o4[q] = pack16<F16>(lo, hi2);
-      }
-      *reinterpret_cast<uint4*>(yh + (size_t)row * d.ldy + c8) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-    }
-    return;
-  }
-  if (wave < RB_BM / 32) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = j * 32 + lrow;
-      const float b2 = d.b2[n];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = tile.row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= tile.seq_end) continue;
-        float v = d.alpha * (acc[j][r] + b2) + d.res_scale * d.x[(size_t)row * d.ldx + n];
-        float* yp = d.y + (size_t)row * d.ldy + n;
-        if (d.accumulate) v += *yp;
-        *yp = v;
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n0 = j * 32 + 8 * rq + 4 * lk;
+          const float4 bb = *reinterpret_cast<const float4*>(d.b2 + n0);
+          float v[4] = {d.alpha * (acc[j][4 * rq] + bb.x), d.alpha * (acc[j][4 * rq + 1] + bb.y), d.alpha * (acc[j][4 * rq + 2] + bb.z),
+                        d.alpha * (acc[j][4 * rq + 3] + bb.w)};
+          if constexpr (IOB) {
+            const uint2 xr = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + n0);
+            v[0] += d.res_scale * from16<F16>(xr.x & 0xFFFF);
+            v[1] += d.res_scale * from16<F16>(xr.x >> 16);
+            v[2] += d.res_scale * from16<F16>(xr.y & 0xFFFF);
+            v[3] += d.res_scale * from16<F16>(xr.y >> 16);
+            uint2* yp = reinterpret_cast<uint2*>(yh + (size_t)row * d.ldy + n0);
+            if (d.accumulate) {
+              const uint2 yr = *yp;
+              v[0] += from16<F16>(yr.x & 0xFFFF);
+              v[1] += from16<F16>(yr.x >> 16);
+              v[2] += from16<F16>(yr.y & 0xFFFF);
+              v[3] += from16<F16>(yr.y >> 16);
+            }
+            *yp = make_uint2(pack16<F16>(v[0], v[1]), pack16<F16>(v[2], v[3]));
+          } else {
+            const float4 xr = *reinterpret_cast<const float4*>(d.x + (size_t)row * d.ldx + n0);
+            v[0] += d.res_scale * xr.x;
+            v[1] += d.res_scale * xr.y;
+            v[2] += d.res_scale * xr.z;
+            v[3] += d.res_scale * xr.w;
+            float4* yp = reinterpret_cast<float4*>(d.y + (size_t)row * d.ldy + n0);
+            if (d.accumulate) {
+              const float4 yr = *yp;
+              v[0] += yr.x;
+              v[1] += yr.y;
+              v[2] += yr.z;
+              v[3] += yr.w;
+            }
+            *yp = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
       }
     }
   }
@@ -540,7 +560,6 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
   const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
   size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2;
-  if (IOB && lds < (size_t)RB_BM * C * 4) lds = (size_t)RB_BM * C * 4;  // fp32 output tile of the coalesced epilogue
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
@@ -550,6 +569,56 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   }
   hipLaunchKernelGGL(k, dim3(d.n_tiles), dim3(RB_THREADS), lds, st, d);
   return launch_status("resblock_step");
+}
+
+// Host mirror of SnakeFir::gen_up / gen_down in the interior of an utterance (no tap folds onto an edge sample): the per-lane
+// A operands [ua0 | ua1 | da0 | da1][64 lanes][8 halfs] the kernel loads in SnakeFir::begin.
+static unsigned short host_f32_to_f16(float f) {  // round to nearest even; the taps are normal numbers well inside fp16's range
+  unsigned int u;
+  memcpy(&u, &f, 4);
+  const unsigned int sign = (u >> 16) & 0x8000u;
+  const int exp = (int)((u >> 23) & 0xFF) - 127 + 15;
+  unsigned int man = u & 0x7FFFFFu;
+  if ((u & 0x7FFFFFFFu) == 0) return (unsigned short)sign;
+  if (exp >= 31) return (unsigned short)(sign | 0x7C00u);
+  if (exp <= 0) {  // subnormal half
+    if (exp < -10) return (unsigned short)sign;
+    man |= 0x800000u;
+    const int shift = 14 - exp;
+    unsigned int h = man >> shift;
+    const unsigned int rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) ++h;
+    return (unsigned short)(sign | h);
+  }
+  unsigned int h = ((unsigned int)exp << 10) | (man >> 13);
+  const unsigned int rem = man & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;  // a carry into the exponent is the correct rounding
+  return (unsigned short)(sign | h);
+}
+
+int snake_fir_table(const float* f, void* table) {
+  TTS_CHECK_ARG(f && table, "snake_fir_table: null pointer");
+  unsigned short* out = static_cast<unsigned short*>(table);
+  for (int lane = 0; lane < 64; ++lane) {
+    const int row = lane & 15, g = lane >> 4;
+    for (int i = 0; i < 2; ++i) {  // up-sampler tile i: outputs n = 2 qo + p, qo = 3 + 8 i + (row >> 1), inputs q = 8 g + j
+      const int qo = 3 + 8 * i + (row >> 1), p = row & 1;
+      for (int j = 0; j < 8; ++j) {
+        const int dq = 8 * g + j - qo;               // x[qo + dq]
+        const int tap = 5 + p - 2 * dq;              // u[2 qo + p] = 2 sum_d x[qo + d] f[5 + p - 2 d]
+        const bool in = p ? (dq >= -2 && dq <= 3) : (dq >= -3 && dq <= 2);
+        out[(i * 64 + lane) * 8 + j] = host_f32_to_f16(in ? 2.0f * f[tap] : 0.0f);
+      }
+    }
+    for (int s = 0; s < 2; ++s) {  // decimator K-step s: y[row] = sum_k s2[2 row + k - 5] f[k], slot (g, j) <-> n = -6 + 32 s + 4 g + j (+ 12)
+      for (int j = 0; j < 8; ++j) {
+        const int n = -6 + 32 * s + 4 * g + j + (j >= 4 ? 12 : 0);
+        const int k = n - 2 * row + 5;
+        out[((2 + s) * 64 + lane) * 8 + j] = host_f32_to_f16((k >= 0 && k <= 11) ? f[k] : 0.0f);
+      }
+    }
+  }
+  return TTS_OK;
 }
 
 int resblock_tile_rows(int c) { return c == 256 ? RbCfg<256>::BM : RbCfg<32>::BM; }
@@ -563,7 +632,10 @@ int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.tile_rows == bm, "resblock_step: tile table must use %d rows for C=%d, got %d", bm, d.c, d.tile_rows);
   TTS_CHECK_ARG(d.act == TTS_PRE_LRELU || d.act == TTS_PRE_SNAKE, "resblock_step: act must be LRELU or SNAKE");
   TTS_CHECK_ARG(d.act != TTS_PRE_SNAKE || (d.alpha1 && d.beta1 && d.alpha2 && d.beta2 && d.filt), "resblock_step: snake parameters missing");
+  TTS_CHECK_ARG(d.act != TTS_PRE_SNAKE || d.c > 128 || d.fir_tab || std::getenv("TOUCAN_SNAKE_VALU"), "resblock_step: fir_tab (tts_snake_fir_table) missing");
   TTS_CHECK_ARG((d.ldx & 3) == 0 && ((uintptr_t)d.x & 15) == 0, "resblock_step: x must be 16-byte aligned rows");
+  TTS_CHECK_ARG(d.io_bf16 || ((d.ldy & 3) == 0 && ((uintptr_t)d.y & 15) == 0), "resblock_step: y must be 16-byte aligned rows");
+  TTS_CHECK_ARG(((uintptr_t)d.b1 & 15) == 0 && ((uintptr_t)d.b2 & 15) == 0, "resblock_step: biases must be 16-byte aligned");
   TTS_CHECK_ARG(!d.io_bf16 || ((d.ldx & 7) == 0 && (d.ldy & 7) == 0 && ((uintptr_t)d.y & 15) == 0), "resblock_step: bf16 rows must be 16-byte aligned");
   TTS_CHECK_ARG(d.compute == 1 || d.compute == 2, "resblock_step: compute must be 1 (bf16) or 2 (fp16), got %d", d.compute);
   if (d.n_tiles == 0) return TTS_OK;

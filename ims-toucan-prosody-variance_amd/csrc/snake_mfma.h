@@ -46,7 +46,7 @@ struct FirTaps {  // the 12 taps by value (register arguments of the out-of-line
 struct SnakeFir {
   // image geometry (16-bit elements): row r of the image <-> local frame frame0 + r; outputs live 6 rows below their inputs' start
   unsigned short* img;
-  int pitch, last_row;  // rows above last_row are never read (addresses are clamped: the surplus only meets zero taps)
+  int pitch;            // rows up to row_begin + 16 n_tiles + 31 are read: the image must hold finite values there (zero taps meet them)
   int frame0, T;
   int ch0;              // first channel of this wavefront's 16-channel block
   int row_begin;        // first raw row of the run: outputs start at row_begin + 6
@@ -107,12 +107,10 @@ struct SnakeFir {
   // B operand of the up-sampler: image rows w .. w + 31, this block's 16 channels (lane: channel = lane & 15, k = 8 (lane >> 4) + j)
   __device__ __forceinline__ bf16x8 load_x(int w, int lane) const {
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    int r0 = w + 8 * g + q, r1 = r0 + 4;
-    r0 = r0 > last_row ? last_row : r0;
-    r1 = r1 > last_row ? last_row : r1;
     typedef tr16x4 __attribute__((address_space(3))) * lds_ptr;
-    const tr16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + r0 * pitch + ch0 + 4 * p));
-    const tr16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(img + r1 * pitch + ch0 + 4 * p));
+    const unsigned short* a = img + (w + 8 * g + q) * pitch + ch0 + 4 * p;
+    const tr16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)a);
+    const tr16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * pitch));
     const bf16x8 x = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return x;
   }
@@ -121,12 +119,15 @@ struct SnakeFir {
   __device__ __forceinline__ bool up_interior(int w) const { return frame0 + w >= 0 && frame0 + w + 21 <= T - 1; }
   __device__ __forceinline__ bool down_interior(int fo) const { return fo >= 3 && fo + 18 <= T - 1; }
 
-  // x window -> 32 2x-rate samples of s as the decimator's B fragment
+  // x window -> 32 2x-rate samples of s as a K-step fragment of the decimator (INNER: no tap folds onto an utterance edge)
+  template <bool INNER>
   __device__ __forceinline__ bf16x8 make_s(const FirTaps& f, const bf16x8& x, int w, int lane) const {
     bf16x8 a0 = ua0, a1 = ua1;
-    if (!up_interior(w)) {  // wave-uniform
-      a0 = gen_up(f, 0, frame0 + w, T, lane);
-      a1 = gen_up(f, 1, frame0 + w, T, lane);
+    if constexpr (!INNER) {
+      if (!up_interior(w)) {  // wave-uniform
+        a0 = gen_up(f, 0, frame0 + w, T, lane);
+        a1 = gen_up(f, 1, frame0 + w, T, lane);
+      }
     }
     const f32x4v z = {0.f, 0.f, 0.f, 0.f};
     const f32x4v u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, x), z, 0, 0, 0);
@@ -142,42 +143,52 @@ struct SnakeFir {
   }
 
   // everything a run needs from rows other wavefronts will overwrite: call before the workgroup barrier that precedes sweep()
-  __device__ __forceinline__ void begin(const FirTaps& f, int lane) {
-    ua0 = gen_up(f, 0, 1 << 20, 1 << 28, lane);
-    ua1 = gen_up(f, 1, 1 << 20, 1 << 28, lane);
-    da0 = gen_down(f, 0, 1 << 20, 1 << 28, lane);
-    da1 = gen_down(f, 1, 1 << 20, 1 << 28, lane);
+  __device__ __forceinline__ void begin(const void* __restrict__ fir_tab, int lane) {
+    // interior constants: built once per filter on the host (snake_fir_table below), one 16-byte load per operand and lane
+    const bf16x8* tab = reinterpret_cast<const bf16x8*>(fir_tab);
+    ua0 = tab[0 * 64 + lane];
+    ua1 = tab[1 * 64 + lane];
+    da0 = tab[2 * 64 + lane];
+    da1 = tab[3 * 64 + lane];
     x_head = load_x(row_begin, lane);
     x_tail = load_x(row_begin + 16 * n_tiles, lane);
   }
 
-  template <bool F16OUT>
-  __device__ __forceinline__ void sweep(const FirTaps& f, int lane) {
-    const int c = lane & 15, g = lane >> 4;
-    bf16x8 s_prev = make_s(f, x_head, row_begin, lane);
-    for (int i = 0; i < n_tiles; ++i) {
+  // The decimator runs TRANSPOSED: y^T = s^T D^T, i.e. the s fragment is the A operand (A[row = channel][k]) and the D fragment
+  // the B operand (B[k][col = frame] has the same lane map as A[row = frame][k]: the same registers serve).  The result then has
+  // the frame on the lane and four consecutive channels in the registers: one 8-byte LDS store per lane instead of four 2-byte ones.
+  template <bool F16OUT, bool INNER>
+  __device__ __forceinline__ void run(const FirTaps& f, int lane) {
+    const int t = lane & 15, g = lane >> 4;
+    bf16x8 s_prev = make_s<INNER>(f, x_head, row_begin, lane);
+    unsigned short* dst = img + (row_begin + 6 + t) * pitch + ch0 + 4 * g;
+    for (int i = 0; i < n_tiles; ++i, dst += 16 * pitch) {
       const int w = row_begin + 16 * (i + 1);
       const bf16x8 x = (i + 1 == n_tiles) ? x_tail : load_x(w, lane);
-      const bf16x8 s_cur = make_s(f, x, w, lane);
-      const int orow = row_begin + 6 + 16 * i, fo = frame0 + orow;
+      const bf16x8 s_cur = make_s<INNER>(f, x, w, lane);
       bf16x8 d0 = da0, d1 = da1;
-      const bool inner = down_interior(fo);
-      if (!inner) {
-        d0 = gen_down(f, 0, fo, T, lane);
-        d1 = gen_down(f, 1, fo, T, lane);
+      if constexpr (!INNER) {
+        const int fo = frame0 + row_begin + 6 + 16 * i;
+        if (!down_interior(fo)) {  // (rows of D for frames outside [0, T) are zero: those outputs are the convs' zero padding)
+          d0 = gen_down(f, 0, fo, T, lane);
+          d1 = gen_down(f, 1, fo, T, lane);
+        }
       }
       f32x4v y = {0.f, 0.f, 0.f, 0.f};
-      y = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, d0), __builtin_bit_cast(f16x8, s_prev), y, 0, 0, 0);
-      y = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, d1), __builtin_bit_cast(f16x8, s_cur), y, 0, 0, 0);
-      unsigned short* dst = img + (orow + 4 * g) * pitch + ch0 + c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int t = fo + 4 * g + r;
-        const float v = (inner || (t >= 0 && t < T)) ? y[r] : 0.0f;
-        dst[r * pitch] = to16<F16OUT>(v);
-      }
+      y = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s_prev), __builtin_bit_cast(f16x8, d0), y, 0, 0, 0);
+      y = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s_cur), __builtin_bit_cast(f16x8, d1), y, 0, 0, 0);
+      *reinterpret_cast<uint2*>(dst) = make_uint2(pack16<F16OUT>(y[0], y[1]), pack16<F16OUT>(y[2], y[3]));
       s_prev = s_cur;
     }
+  }
+
+  template <bool F16OUT>
+  __device__ __forceinline__ void sweep(const FirTaps& f, int lane) {
+    // interior frames form one range: the run is interior iff its first and last windows / output tiles are
+    const bool inner = up_interior(row_begin) && up_interior(row_begin + 16 * n_tiles) && down_interior(frame0 + row_begin + 6) &&
+                       down_interior(frame0 + row_begin + 6 + 16 * (n_tiles - 1));
+    if (inner) run<F16OUT, true>(f, lane);
+    else run<F16OUT, false>(f, lane);
   }
 };
 

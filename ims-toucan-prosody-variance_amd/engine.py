@@ -71,6 +71,7 @@ class Ops:
                                       f"interface with device='cuda' (the reference's default 'cpu' cannot be served)")
         self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
         self.small_tile_blocks = int(os.environ.get("TOUCAN_SMALL_TILE_BLOCKS", "1536"))  # regular conv grids below this many workgroups switch to the 64 x 64 small-batch form (0: never)
+        self._fir_tabs = {}
         self.default_compute = COMPUTE_F32  # convs whose weights carry a 16-bit copy run on bf16 / fp16 MFMA when this is not COMPUTE_F32
 
     def stream(self):
@@ -126,7 +127,7 @@ class Ops:
         return y
 
     def resblock_step(self, c1, c2, x, y, rag, act, slope=0.1, snake1=None, snake2=None, filt=None, alpha=1.0, res_scale=1.0,
-                      accumulate=False):
+                      accumulate=False, fir_tab=None):
         """Fused residual step (tts_resblock_step): y = alpha*conv2(act(conv1(act(x)))) + res_scale*x (+ y)."""
         tile_rows = self.lib.tts_resblock_tile_rows(c1.cin)
         tiles, n_tiles = rag.tiles(tile_rows)
@@ -141,6 +142,12 @@ class Ops:
             d.alpha1, d.beta1 = snake1[0].data_ptr(), snake1[1].data_ptr()
             d.alpha2, d.beta2 = snake2[0].data_ptr(), snake2[1].data_ptr()
             d.filt = filt.data_ptr()
+            if fir_tab is None:  # callers without a prepared table (tests, micro-benchmarks): built once per filter tensor
+                key = (filt.data_ptr(), str(filt.device))
+                if key not in self._fir_tabs:
+                    self._fir_tabs[key] = (packing.snake_fir_table(filt.detach().cpu().numpy(), filt.device), filt)
+                fir_tab = self._fir_tabs[key][0]
+            d.fir_tab = fir_tab.data_ptr()
         d.alpha, d.res_scale, d.accumulate = alpha, res_scale, 1 if accumulate else 0
         assert x.dtype == y.dtype and (not _is_bf16(x) or (x.dtype == torch.float16) == (c1.compute16 == COMPUTE_F16))
         d.io_bf16 = 1 if _is_bf16(x) else 0
@@ -751,7 +758,9 @@ class VocoderEngine:
         if kind == "bigvgan":
             self.post_snake = (_dev(sd["activation_post.act.alpha"], dev), _dev(sd["activation_post.act.beta"], dev))
             stored = packing.stored_antialias_filter(sd)  # real checkpoints carry the filter as buffers; fixtures do not
-            self.filt = _dev(packing.kaiser_sinc_filter12() if stored is None else stored, dev)
+            taps = packing.kaiser_sinc_filter12() if stored is None else stored
+            self.filt = _dev(taps, dev)
+            self.fir_tab = packing.snake_fir_table(taps, dev)  # the same filter as matrix-core operands (fused residual steps)
 
     @torch.inference_mode()
     def forward(self, mel_packed, rag, taps=None):
@@ -794,7 +803,8 @@ class VocoderEngine:
                         sn1, sn2 = self.snakes[i][j][dd] if big else (None, None)
                         dst = stage_out if last else bufs[dd % 2]
                         ops.resblock_step(c1, c2, cur, dst, rag, PRE_SNAKE if big else PRE_LRELU, 0.1, sn1, sn2, self.filt if big else None,
-                                          alpha=1.0 / 3.0 if last else 1.0, res_scale=1.0 / 3.0 if last else 1.0, accumulate=last and j > 0)
+                                          alpha=1.0 / 3.0 if last else 1.0, res_scale=1.0 / 3.0 if last else 1.0, accumulate=last and j > 0,
+                                          fir_tab=self.fir_tab if big else None)
                         cur = dst
                         continue
                     if big:  # AMP.py:51-60: a1 -> c1 -> a2 -> c2 -> + x; both activations run inside the convs' input staging

@@ -170,6 +170,16 @@ def stored_antialias_filter(sd):
     return first
 
 
+def snake_fir_table(filt, device):
+    """The anti-alias filter as matrix-core operands for the fused residual step (tts_snake_fir_table, csrc/snake_mfma.h)."""
+    import ctypes
+    f = np.ascontiguousarray(filt, dtype=np.float32)
+    assert f.size == 12
+    buf = np.zeros(4096, dtype=np.uint8)
+    capi.check(capi.lib().tts_snake_fir_table(f.ctypes.data_as(ctypes.c_void_p), buf.ctypes.data_as(ctypes.c_void_p)), "tts_snake_fir_table")
+    return torch.from_numpy(buf).to(device)
+
+
 def kaiser_sinc_filter12():
     """alias_free_torch's kaiser_sinc_filter1d(cutoff 0.25, half_width 0.3, 12 taps) - third party, PARITY UNPINNED.
     A = 2.285*(K/2-1)*pi*4*half_width + 7.95; beta from Kaiser's formula; h = 2c*w*sinc(2c*t), normalised to sum 1."""

@@ -125,7 +125,14 @@ typedef struct {
   int32_t io_bf16; /* 1: x and y are 16-bit tensors in HBM, in the format of `compute` (halves the traffic of this bandwidth-bound step) */
   const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows;
   int32_t compute; /* TTS_COMPUTE_BF16 or TTS_COMPUTE_F16: element format of the weights, the LDS tiles and 16-bit x / y */
+  const void* fir_tab; /* TTS_PRE_SNAKE, C <= 128: device copy of tts_snake_fir_table(filt) (the filters as matrix-core operands) */
 } TtsResblockDesc;
+
+/* The anti-alias filter as the per-lane A operands of the fused step's matrix-core FIR stages (csrc/snake_mfma.h): the banded
+ * Toeplitz matrices of the 2x up-sampler and of the decimator, as fp16 fragments [4 operands][64 lanes][8 halfs] =
+ * TTS_SNAKE_FIR_TABLE_BYTES bytes.  Pure host arithmetic on host pointers (no GPU, no stream); upload the result once per filter. */
+#define TTS_SNAKE_FIR_TABLE_BYTES 4096
+int tts_snake_fir_table(const float* filt /*[12], host*/, void* table /*host, TTS_SNAKE_FIR_TABLE_BYTES*/);
 
 /* rows per tile the fused step uses for C channels (224 for C <= 128, 96 for C = 256): build the tile table with it */
 int tts_resblock_tile_rows(int32_t c);

@@ -199,6 +199,9 @@ class Emulator:
             _store(d.y, sb, se, d.cout, d.ldy, v, fy)
         return 0
 
+    def tts_snake_fir_table(self, filt, table):
+        return self._reallib().tts_snake_fir_table(filt, table)  # host-only arithmetic: the real library's (the emulator ignores the table)
+
     def tts_resblock_tile_rows(self, c):
         return self._reallib().tts_resblock_tile_rows(c)
 

@@ -17,25 +17,36 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=640)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--store", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--store", default="fp32", choices=["fp32", "bf16", "f16"])
+    ap.add_argument("--channels", default="256,128,64,32", help="comma list of channel counts to run")
+    ap.add_argument("--taps", default="3,7,11", help="comma list of kernel sizes to run")
+    ap.add_argument("--acts", default="lrelu,snake")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ops = engine.Ops(dev)
     filt = torch.from_numpy(packing.kaiser_sinc_filter12()).to(dev)
     print(f"{'C':>4} {'k':>3} {'dil':>3} {'act':>6} {'us':>9} {'TFLOP/s':>8} {'GB/s(x+y)':>9}")
+    want = {int(c) for c in args.channels.split(",")}
+    pk = "f16" if args.store == "f16" else True
     for C, mult in ((256, 8), (128, 48), (64, 192), (32, 384)):
+        if C not in want:
+            continue
         rows = args.frames * mult
         rag = Ragged([rows] * args.batch, dev)
         R = rag.total_rows
-        sdt = torch.bfloat16 if args.store == "bf16" else torch.float32
+        sdt = {"bf16": torch.bfloat16, "f16": torch.float16, "fp32": torch.float32}[args.store]
         x = torch.randn(R, C, device=dev).to(sdt)
         y = torch.empty(R, C, device=dev, dtype=sdt)
         sn = (torch.zeros(C, device=dev), torch.zeros(C, device=dev))
         for k, dil in ((3, 1), (7, 3), (11, 5)):
+            if str(k) not in args.taps.split(","):
+                continue
             rs = np.random.RandomState(0)
-            c1 = packing.pack_conv((rs.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32), np.zeros(C, np.float32), dev, dil=dil, bf16=True)
-            c2 = packing.pack_conv((rs.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32), np.zeros(C, np.float32), dev, dil=1, bf16=True)
+            c1 = packing.pack_conv((rs.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32), np.zeros(C, np.float32), dev, dil=dil, bf16=pk)
+            c2 = packing.pack_conv((rs.randn(C, C, k) / np.sqrt(C * k)).astype(np.float32), np.zeros(C, np.float32), dev, dil=1, bf16=pk)
             for act, name in ((capi.PRE_LRELU, "lrelu"), (capi.PRE_SNAKE, "snake")):
+                if name not in args.acts.split(","):
+                    continue
                 run = lambda: ops.resblock_step(c1, c2, x, y, rag, act, 0.1, sn, sn, filt)
                 run()
                 torch.cuda.synchronize()
