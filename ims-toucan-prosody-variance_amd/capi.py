@@ -61,6 +61,10 @@ class TtsResblockDesc(C.Structure):
     ]
 
 
+class TtsConfig(C.Structure):
+    _fields_ = [("multilingual", _i), ("multispeaker", _i), ("vocoder", _i), ("precision", _i), ("small_tile_blocks", _i), ("post_bias", _f)]
+
+
 IO_X_BF16, IO_Y_BF16, IO_RES_BF16, IO_F16 = 1, 2, 4, 8
 
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
@@ -92,11 +96,29 @@ PROTOTYPES = {
     "tts_conv_post_snake_tile_rows": (C.c_int, []),
     "tts_conv_post_snake": (C.c_int, [_p, _i, _i, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tts_gather_rows": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _p]),
+    # stage API (csrc/pipeline.hip)
+    "tts_create": (C.c_int, [C.POINTER(TtsConfig), C.POINTER(_p)]),
+    "tts_destroy": (C.c_int, [_p]),
+    "tts_load_weights": (C.c_int, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _i]),
+    "tts_workspace_bytes": (C.c_int64, [_p, _i, _i, _i]),
+    "tts_encoder": (C.c_int, [_p, _p, _p, _p, _p, _i, _p]),
+    "tts_variance_predictors": (C.c_int, [_p, _p, _p, _p, _p]),
+    "tts_control_and_regulate": (C.c_int, [_p, _f, _f, _f, _f, _p, _p]),
+    "tts_decoder": (C.c_int, [_p, _p]),
+    "tts_postnet": (C.c_int, [_p, _p]),
+    "tts_postflow": (C.c_int, [_p, _p, _p]),
+    "tts_mel": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_i), _p, _p]),
+    "tts_prosody": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
+    "tts_copy_mel": (C.c_int, [_p, _p, _i, _p]),
+    "tts_copy_prosody": (C.c_int, [_p, _p, _p, _p, _p]),
+    "tts_vocoder_bigvgan": (C.c_int, [_p, _p, _i, _p, _p, _i, _p, _p]),
+    "tts_vocoder_hifigan": (C.c_int, [_p, _p, _i, _p, _p, _i, _p, _p]),
+    "tts_synthesize_batch": (C.c_int, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, C.c_int64, C.POINTER(C.c_int64), _p]),
     "tts_axpby": (C.c_int, [_p, _i, _f, _p, _i, _f, _p, _i, _i, _i, _p]),
 }
 
 _LIB = None
-ABI_VERSION = 7  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 8  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

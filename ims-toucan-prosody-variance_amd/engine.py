@@ -341,18 +341,19 @@ class ConformerWeights:
 class AcousticEngine:
     """InferenceToucanTTS.ToucanTTS (:16-319) for a ragged batch of utterances."""
 
-    def __init__(self, state_dict, device, bf16=False, use_graphs=False, precision=None):
+    def __init__(self, state_dict, device, bf16=False, use_graphs=False, precision=None, pack_only=False):
         """precision "bf16" (or bf16=True): Conformer / PostNet / PostFlow GEMMs on bf16 MFMA with fp32 accumulation and fp32
         activations (BASELINE.json configs[2]); "f16": the same GEMMs on fp16 MFMA (configs[4]).  In both, the variance predictors,
         all norms, softmax, the coupling output conv and the flow state stay fp32 (fp16 exp(-logs) chains
         over 18 blocks overflow otherwise)."""
-        self.ops = Ops(device)
-        self.device = self.ops.device
+        # pack_only: only the weight preparation (host tensors for native.NativePipeline to upload), no launch machinery
+        self.ops = None if pack_only else Ops(device)
+        self.device = torch.device(device) if pack_only else self.ops.device
         self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
         self.bf16 = bool(bf16)  # a 16-bit MFMA configuration (either format)
         self.use_graphs = use_graphs
         self._graphs = GraphCache(self.device)
-        if bf16:
+        if bf16 and self.ops is not None:
             self.ops.default_compute = compute16
         dev = self.device
         sd = packing.fold_weight_norm(state_dict)
@@ -393,7 +394,7 @@ class AcousticEngine:
         self.n_cln_mlp = len(cln_blocks)
         if cln_blocks:
             self.cln_weights = _dev(np.concatenate(cln_blocks), dev)
-            assert cln_blocks[0].size == self.ops.lib.tts_cln_mlp_weight_floats(64, 256)
+            assert cln_blocks[0].size == capi.lib().tts_cln_mlp_weight_floats(64, 256)
         self.pitch_w = _dev(sd["pitch_embed.0.weight"].reshape(-1), dev)
         self.pitch_b = _dev(sd["pitch_embed.0.bias"], dev)
         self.energy_w = _dev(sd["energy_embed.0.weight"].reshape(-1), dev)
@@ -708,7 +709,7 @@ class VocoderEngine:
     DIL = (1, 3, 5)
 
     def __init__(self, state_dict, kind, device, bf16=False, fuse_snake=False, fuse_step=None, store_bf16=None, use_graphs=False,
-                 precision=None):
+                 precision=None, pack_only=False):
         assert kind in ("bigvgan", "hifigan")
         self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
         self.kind = kind
@@ -724,8 +725,8 @@ class VocoderEngine:
         # unfused convs + stand-alone snakes (9.1 vs 9.0 ms per step measured), so stage 1 keeps the unfused path
         self.fuse_max_channels = 128
         self.store_bf16 = self.fuse_step if store_bf16 is None else (store_bf16 and self.fuse_step)
-        self.ops = Ops(device)
-        self.device = self.ops.device
+        self.ops = None if pack_only else Ops(device)
+        self.device = torch.device(device) if pack_only else self.ops.device
         self.compute = compute16
         dev = self.device
         sd = packing.fold_weight_norm(state_dict)

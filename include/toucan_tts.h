@@ -235,10 +235,86 @@ int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz,
 int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst, int32_t n,
                     int32_t c, tts_stream_t stream);
 
+/* =====================================================================================================================
+ * Stage API: a handle that owns the packed weights and the workspace, and one call per stage of the reference's forward pass
+ * (csrc/pipeline.hip sequences the kernels above in C++).  One handle per (process, device); calls on a
+ * handle are serialised by the caller's stream.  All pointers are device pointers unless marked host.  Allocation happens only
+ * inside the handle (weights, workspace arenas that grow to the largest batch seen, cached tile tables).
+ *
+ * Mirrors: tts_encoder = Conformer.forward on the phoneme features (Layers/Conformer.py:92-134, InferenceToucanTTS.py:202-206);
+ * tts_variance_predictors = VariancePredictor / DurationPredictor (InferenceToucanTTS.py:209-211); tts_control_and_regulate =
+ * the control loop, _scale_variance and the LengthRegulator (InferenceToucanTTS.py:214-235, :333-343, LengthRegulator.py:37-61);
+ * tts_decoder = decoder Conformer + feat_out (:238-239); tts_postnet (:241, PostNet.py:62-74); tts_postflow = Glow.forward(infer)
+ * with the noise as an explicit input (:244-248, Glow.py:342-391); tts_vocoder_* = InferenceBigVGAN.py:72-95 /
+ * InferenceAvocodo.py:69-80; tts_synthesize_batch = ToucanTTS.forward + the vocoder for a ragged batch
+ * (ToucanTTSInterface.py:157-169 run once per utterance).
+ * ===================================================================================================================== */
+typedef struct TtsHandle TtsHandle;
+
+typedef struct {
+  int32_t multilingual;       /* checkpoint has encoder.language_embedding (ToucanTTSInterface.py:55-60) */
+  int32_t multispeaker;       /* checkpoint has utterance-embedding conditioning (else plain LayerNorm predictors, :61-63) */
+  int32_t vocoder;            /* 0 none, 1 Avocodo / HiFiGAN generator, 2 BigVGAN */
+  int32_t precision;          /* TTS_COMPUTE_*: MFMA path of the GEMMs that carry a 16-bit weight copy; statistics stay fp32 */
+  int32_t small_tile_blocks;  /* conv grids below this many workgroups use the 64-row small-batch tiles (0: default 1536) */
+  float post_bias;            /* bias of the vocoder's output conv */
+} TtsConfig;
+
+int tts_create(const TtsConfig* cfg, TtsHandle** out);
+int tts_destroy(TtsHandle* h);
+
+/* Upload one packed tensor under `name` (a later call with the same name replaces it).  dtype: 0 f32, 1 bf16, 2 f16, 4 u8 are
+ * copied to the device; 3 = int32 host metadata (the descriptor fields of a packed conv, kept on the host).
+ * A packed conv "<n>" is the group "<n>.w" [taps][cin_pad][wn] f32, optional "<n>.w16" [taps][cin_pad/8][wn][8], optional
+ * "<n>.bias", and "<n>.meta" = int32[16] {mode, taps, dil, pad_left, cin, cin_pad, cout, wn, half_pad, tile_rows,
+ * small_tile_rows, small_only, n_tile, compute16, 0, 0} (see tts_conv1d).  Names: INTEGRATION.md lists them; the host packer is
+ * ims-toucan-prosody-variance_amd/native.py. */
+int tts_load_weights(TtsHandle* h, const char* name, const void* host_ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
+
+/* Upper bound of the workspace a batch of B utterances of at most Lmax phonemes / Tmax frames will claim (bytes). */
+int64_t tts_workspace_bytes(const TtsHandle* h, int32_t B, int32_t Lmax, int32_t Tmax);
+
+/* text: packed phoneme features [sum L, 62]; utt_emb [B, 64] (NULL for the single-speaker variant); lang_ids [B] (NULL: no
+ * language embedding); phone_lengths: host [B].  Starts a batch: later stages work on the handle's state. */
+int tts_encoder(TtsHandle* h, const float* text, const float* utt_emb, const int32_t* lang_ids, const int32_t* phone_lengths /*host*/,
+                int32_t B, tts_stream_t stream);
+/* gold_*: packed per-phoneme values replacing a prediction (ToucanTTSInterface.py:139-141), or NULL to predict. */
+int tts_variance_predictors(TtsHandle* h, const float* gold_pitch, const float* gold_energy, const int32_t* gold_durations,
+                            tts_stream_t stream);
+/* Applies the linguistic overrides and the four scaling factors, reads the integer durations back (the pass's one host round
+ * trip), sizes the frame buffers and expands the phoneme rows.  frame_counts (host [B], may be NULL) receives the frames per utterance. */
+int tts_control_and_regulate(TtsHandle* h, float duration_scale, float pitch_scale, float energy_scale, float pause_scale,
+                             int32_t* frame_counts /*host*/, tts_stream_t stream);
+int tts_decoder(TtsHandle* h, tts_stream_t stream);
+int tts_postnet(TtsHandle* h, tts_stream_t stream);
+/* z_noise: the 0.8 N(0,1) sample (Glow.py:363) in the squeezed frame layout, [total_frames / 2, 160]: row frame_begin[u]/2 + i of
+ * utterance u holds frames 2i and 2i+1 (80 channels each). */
+int tts_postflow(TtsHandle* h, const float* z_noise, tts_stream_t stream);
+/* Where the batch's mel is: packed rows of 80 channels with row stride *ld; utterance u starts at frame_begins[u] (host [B], even)
+ * and has frame_counts[u] frames (an odd count loses its last frame once the flow has run, glow_utils.py:31-32). */
+int tts_mel(TtsHandle* h, const float** mel, int32_t* ld, int32_t* frame_begins /*host*/, int32_t* frame_counts /*host*/);
+/* Copies the batch's mel (all packed rows, 80 channels) into dst with row stride ld_dst (floats). */
+int tts_copy_mel(TtsHandle* h, float* dst, int32_t ld_dst, tts_stream_t stream);
+/* Packed per-phoneme durations / pitch / energy of the batch after the control step (device pointers into the workspace). */
+int tts_prosody(TtsHandle* h, const int32_t** durations, const float** pitch, const float** energy);
+/* The same, copied into caller buffers of sum(phone_lengths) elements each (any of them may be NULL). */
+int tts_copy_prosody(TtsHandle* h, int32_t* durations, float* pitch, float* energy, tts_stream_t stream);
+/* mel: packed [rows, 80] with row stride ld_mel; wav: packed, utterance u at 384 * frame_begins[u], 384 * frame_counts[u] samples. */
+int tts_vocoder_bigvgan(TtsHandle* h, const float* mel, int32_t ld_mel, const int32_t* frame_begins /*host*/,
+                        const int32_t* frame_counts /*host*/, int32_t B, float* wav, tts_stream_t stream);
+int tts_vocoder_hifigan(TtsHandle* h, const float* mel, int32_t ld_mel, const int32_t* frame_begins /*host*/,
+                        const int32_t* frame_counts /*host*/, int32_t B, float* wav, tts_stream_t stream);
+/* The whole pass.  z_noise NULL: the flow is skipped; wav NULL: no vocoder.  *wav_needed (may be NULL) receives the samples the
+ * packed waveform takes; a too small wav_capacity is TTS_E_ARG (the mel stays available through tts_mel). */
+int tts_synthesize_batch(TtsHandle* h, const float* text, const float* utt_emb, const int32_t* lang_ids, const int32_t* phone_lengths /*host*/,
+                         int32_t B, const float* gold_pitch, const float* gold_energy, const int32_t* gold_durations, float duration_scale,
+                         float pitch_scale, float energy_scale, float pause_scale, const float* z_noise, int32_t* frame_begins /*host*/,
+                         int32_t* frame_counts /*host*/, float* wav, int64_t wav_capacity, int64_t* wav_needed /*host*/, tts_stream_t stream);
+
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 7
+#define TTS_ABI_VERSION 8
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,161 @@
+"""The stage API (include/toucan_tts.h: tts_create ... tts_synthesize_batch; csrc/pipeline.hip sequences the kernels in C++)
+on a real MI355X, through ctypes:
+ (1) against the committed reference goldens (tests/golden/*.npz) with the fp32 tolerances of test_gpu_e2e.py, and
+ (2) against the Python-sequenced engines (engine.py), which launch the same kernels in the same order: bit-identical."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ims_toucan_prosody_variance_amd  # noqa: F401
+from ims_toucan_prosody_variance_amd import capi, engine, fixture_weights as fw, native, synthetic as syn
+from ims_toucan_prosody_variance_amd.ragged import Ragged
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _gold(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def _inputs(gs):
+    texts = [torch.from_numpy(g["text"]) for g in gs]
+    embs = torch.stack([torch.from_numpy(g["utt_emb"]) for g in gs])
+    langs = [int(g["lang_id"]) for g in gs]
+    zs = [torch.from_numpy(g["z"]) for g in gs]
+    return texts, embs, langs, zs
+
+
+@pytest.fixture(scope="module")
+def pipes():
+    assert torch.cuda.is_available()
+    ac = fw.acoustic_state_dict()
+    return {k: native.NativePipeline(ac, sd, k, DEV) for k, sd in (("hifigan", fw.hifigan_state_dict()), ("bigvgan", fw.bigvgan_state_dict()))}
+
+
+@pytest.mark.parametrize("name", ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "L128_gold5"])
+def test_stage_api_matches_reference_golden(pipes, name):
+    g = _gold(name)
+    texts, embs, langs, zs = _inputs([g])
+    kw = json.loads(str(g["ctrl"]))
+    if "gold_durations" in g.files:
+        kw["durations"] = [torch.from_numpy(g["gold_durations"])]
+    out = pipes["hifigan"].forward(texts, embs, langs, z_noise=zs, **kw)
+    assert np.array_equal(out["durations"][0].cpu().numpy(), g["durations"]), "durations must be bit exact"
+    np.testing.assert_allclose(out["pitch"][0].cpu().numpy(), g["pitch"], atol=5e-5)
+    np.testing.assert_allclose(out["energy"][0].cpu().numpy(), g["energy"], atol=5e-5)
+    mel = out["mel"][0].cpu().numpy()
+    assert mel.shape == g["mel"].shape
+    err = np.abs(mel - g["mel"])
+    assert err.max() < 5e-4 and err.mean() < 1e-4, (float(err.max()), float(err.mean()))
+    if "wav_hifigan" in g.files:
+        b, n = out["wav_spans"][0]
+        assert np.abs(out["wav"][b:b + n].cpu().numpy() - g["wav_hifigan"]).max() < 5e-4
+
+
+@pytest.mark.parametrize("kind", ["hifigan", "bigvgan"])
+def test_stage_api_vocoders_match_reference_golden(pipes, kind):
+    for name in ("L7_pred", "L20_pred"):
+        g = _gold(name)
+        mel = torch.from_numpy(g["mel"]).to(DEV).contiguous()
+        wav, rag = pipes[kind].vocode(mel, Ragged([mel.shape[0]], DEV))
+        assert np.abs(wav.cpu().numpy()[: rag.lengths[0]] - g["wav_" + kind]).max() < 5e-4, (kind, name)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16", "f16"])
+def test_stage_api_is_bit_identical_to_the_python_sequencer(precision):
+    """Ragged 4-batch (goldens R128/R97/R64/R20, gold durations) + BigVGAN: C++ sequencing == Python sequencing, bit for bit,
+    in every precision (same kernels, same order, same tile-form decisions)."""
+    gs = [_gold(n) for n in ("R128", "R97", "R64", "R20")]
+    texts, embs, langs, zs = _inputs(gs)
+    durs = [torch.from_numpy(g["gold_durations"]) for g in gs]
+    ac_sd, voc_sd = fw.acoustic_state_dict(), fw.bigvgan_state_dict()
+    pipe = native.NativePipeline(ac_sd, voc_sd, "bigvgan", DEV, precision=precision)
+    ac = engine.AcousticEngine(ac_sd, DEV, precision=precision)
+    voc = engine.VocoderEngine(voc_sd, "bigvgan", DEV, precision=precision)
+    kw = dict(pitch_variance_scale=1.3, energy_variance_scale=0.7)
+    ref = ac.forward(texts, embs, langs, durations=durs, z_noise=zs, **kw)
+    wref, rw = voc.forward(ref["mel_packed"], ref["rag_mel"])
+    out = pipe.forward(texts, embs, langs, durations=durs, z_noise=zs, **kw)
+    for u in range(4):
+        assert torch.equal(out["pitch"][u], ref["pitch"][u])
+        assert torch.equal(out["mel"][u], ref["mel"][u]), f"utterance {u}: max diff {float((out['mel'][u] - ref['mel'][u]).abs().max()):.3e}"
+        b, n = out["wav_spans"][u]
+        assert (b, n) == (rw.begins[u], rw.lengths[u])
+        assert torch.equal(out["wav"][b:b + n], wref[b:b + n]), f"utterance {u}: waveform differs"
+
+
+def test_predicted_durations_and_variants_through_the_stage_api():
+    """Predicted durations (duration predictor + control + host round trip inside tts_control_and_regulate) on a seeded batch, and
+    the single-speaker checkpoint variant (plain LayerNorm predictors, no utterance embedding) - both equal to the Python sequencer."""
+    us, Ls = [300, 301, 302], [48, 21, 33]
+    feats = [torch.from_numpy(syn.utterance_features(u, L)) for u, L in zip(us, Ls)]
+    embs = torch.from_numpy(np.stack([syn.utterance_embedding(u) for u in us]))
+    kw = dict(duration_scaling_factor=0.9, pitch_variance_scale=1.2, energy_variance_scale=0.8, pause_duration_scaling_factor=1.3)
+    gen = lambda: torch.Generator(device=DEV).manual_seed(5)
+    for sd, langs in ((fw.acoustic_state_dict(), [syn.LANG_EN] * 3),):
+        pipe = native.NativePipeline(sd, None, None, DEV)
+        ac = engine.AcousticEngine(sd, DEV)
+        ref = ac.forward(feats, embs, langs, generator=gen(), **kw)
+        out = pipe.forward(feats, embs, langs, generator=gen(), **kw)
+        assert torch.equal(out["durations_packed"], ref["durations_packed"])
+        for u in range(3):
+            assert torch.equal(out["mel"][u], ref["mel"][u])
+    # checkpoint variants (ToucanTTSInterface.py:55-63) against their reference goldens, through the stage API
+    for name in ("V20_monolingual", "V20_single"):
+        g = _gold(name)
+        sd = fw.acoustic_state_dict(**json.loads(str(g["fixture"])))
+        pipe = native.NativePipeline(sd, None, None, DEV)
+        assert pipe.multilingual is False and pipe.multispeaker is (name == "V20_monolingual")
+        out = pipe.forward([torch.from_numpy(g["text"])], torch.from_numpy(g["utt_emb"])[None], [int(g["lang_id"])], z_noise=[torch.from_numpy(g["z"])])
+        assert np.array_equal(out["durations"][0].cpu().numpy(), g["durations"])
+        err = np.abs(out["mel"][0].cpu().numpy() - g["mel"])
+        assert err.max() < 5e-4 and err.mean() < 1e-4, name
+
+
+def test_synthesize_batch_one_call_and_error_paths(pipes):
+    """tts_synthesize_batch through ctypes: the whole pass in ONE call; too small a waveform buffer and a missing weight come back
+    as error codes with a message."""
+    pipe = pipes["hifigan"]
+    lib, h = pipe.lib, pipe.h
+    gs = [_gold("L20_pred"), _gold("L7_pred")]
+    texts, embs, langs, zs = _inputs(gs)
+    ref = pipe.forward(texts, embs, langs, z_noise=zs)
+    B = 2
+    text = torch.cat(texts).to(DEV).contiguous()
+    emb = embs.to(DEV).contiguous()
+    lang = torch.tensor(langs, dtype=torch.int32, device=DEV)
+    lens = (C.c_int32 * B)(*[int(t.shape[0]) for t in texts])
+    rag_s = ref["rag_frame"].halved()
+    z_sq = torch.zeros(ref["rag_frame"].total_rows // 2, 160, device=DEV)
+    for zu, b0, n in zip(zs, rag_s.begins, rag_s.lengths):
+        z_sq[b0:b0 + n].copy_(zu.t()[: 2 * n].reshape(n, 160))
+    fb, fc = (C.c_int32 * B)(), (C.c_int32 * B)()
+    need = C.c_int64()
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: C.c_void_p(t.data_ptr())
+    tiny = torch.empty(16, device=DEV)
+    rc = lib.tts_synthesize_batch(h, p(text), p(emb), p(lang), lens, B, None, None, None, 1.0, 1.0, 1.0, 1.0, p(z_sq), fb, fc, p(tiny), 16,
+                                  C.byref(need), st)
+    assert rc != 0 and b"samples" in lib.tts_last_error() and need.value == ref["wav"].numel()
+    wav = torch.empty(need.value, device=DEV)
+    rc = lib.tts_synthesize_batch(h, p(text), p(emb), p(lang), lens, B, None, None, None, 1.0, 1.0, 1.0, 1.0, p(z_sq), fb, fc, p(wav),
+                                  need.value, C.byref(need), st)
+    assert rc == 0, lib.tts_last_error()
+    torch.cuda.synchronize()
+    for u in range(B):
+        b, n = ref["wav_spans"][u]
+        assert (384 * fb[u], 384 * fc[u]) == (b, n)
+        assert torch.equal(wav[b:b + n], ref["wav"][b:b + n])
+    # a handle without weights reports what is missing
+    h2 = C.c_void_p()
+    cfg = capi.TtsConfig(1, 1, 0, 0, 0, 0.0)
+    assert lib.tts_create(C.byref(cfg), C.byref(h2)) == 0
+    assert lib.tts_encoder(h2, p(text), p(emb), p(lang), lens, B, st) != 0 and b"was not loaded" in lib.tts_last_error()
+    assert lib.tts_destroy(h2) == 0
+    assert pipe.workspace_bytes(32, 128, 640) > pipe.workspace_bytes(1, 128, 640) > 0
