@@ -29,7 +29,9 @@ sys.path.insert(0, ROOT)
 PEAK_F32_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 PEAK_16BIT_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (6.3 TB/s is what a streaming copy reaches)
-PEAK_VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # lane-operations/s: 256 CUs x 4 SIMD-32 at 2.4 GHz (one wave64 instruction = 2 cycles)
+# vector lane-operations/s: 256 CUs x 4 SIMDs x 16 lanes per cycle at 2.4 GHz.  Measured on these kernels (profiles/r02_*_SQ*):
+# SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.1 quad-cycles, i.e. a wave64 vector instruction holds its SIMD's issue for ~4 cycles
+PEAK_VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
 
 
 def parse_args():
@@ -49,6 +51,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
     ap.add_argument("--graphs", action="store_true", help="replay the shape-static stages as HIP graphs (no per-kernel roofline leg)")
+    ap.add_argument("--sequencer", default="native", choices=["native", "python"],
+                    help="native: the stage API (csrc/pipeline.hip sequences the kernels in C++; the product path); python: engine.py issues "
+                         "every kernel-level call itself")
     return ap.parse_args()
 
 
@@ -142,7 +147,7 @@ def main():
     import torch.distributed as dist
 
     import ims_toucan_prosody_variance_amd  # noqa: F401
-    from ims_toucan_prosody_variance_amd import capi, engine, fixture_weights as fw, profiling, synthetic as syn
+    from ims_toucan_prosody_variance_amd import capi, engine, fixture_weights as fw, native, profiling, synthetic as syn
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,9 +170,13 @@ def main():
 
     precision = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype]
     log(f"building engines (fixture weights, {precision})")
-    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, precision=precision, use_graphs=args.graphs)
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
-    voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, precision=precision, fuse_snake=args.fuse_snake, use_graphs=args.graphs)
+    use_native = args.sequencer == "native" and not args.graphs and not args.fuse_snake
+    if use_native:
+        pipe = native.NativePipeline(fw.acoustic_state_dict(), voc_sd, args.vocoder, dev, precision=precision)
+    else:
+        ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, precision=precision, use_graphs=args.graphs)
+        voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, precision=precision, fuse_snake=args.fuse_snake, use_graphs=args.graphs)
 
     B, L, T = args.batch, args.phones, args.phones * args.frames_per_phone
     log(f"synthetic inputs: {B} x {L} phonemes -> {T} frames per utterance")
@@ -189,10 +198,16 @@ def main():
     def step(record=False, tx=texts, em=embs, zz=zs):
         if record:
             ev[0].record()
-        out = ac.forward(tx, em, langs, durations=durs, z_noise=zz, **scales)
+        if use_native:
+            out = pipe.forward(tx, em, langs, durations=durs, z_noise=zz, vocode=False, **scales)
+        else:
+            out = ac.forward(tx, em, langs, durations=durs, z_noise=zz, **scales)
         if record:
             ev[1].record()
-        wav, rag = voc.forward(out["mel_packed"], out["rag_mel"])
+        if use_native:
+            wav, _ = pipe.vocode_batch(out["rag_mel"])
+        else:
+            wav, rag = voc.forward(out["mel_packed"], out["rag_mel"])
         if record:
             ev[2].record()
         if world > 1:  # one exchange step: waveforms of all ranks (equal length here) over RCCL/xGMI
@@ -205,7 +220,17 @@ def main():
     step()
     torch.cuda.synchronize()
     classes, dominant = {}, None
-    if not args.graphs:
+    if use_native:
+        pipe.profile(True, None)
+        log("warm-up step 2 (all MFMA kernel classes timed inside the stage entries)")
+        calls0 = capi.CALLS
+        step()
+        torch.cuda.synchronize()
+        abi_calls = capi.CALLS - calls0
+        classes = pipe.profile_summary()
+        dominant = max(classes, key=lambda k: classes[k]["total_ms"]) if classes else None
+        pipe.profile(False)
+    elif not args.graphs:
         timer = profiling.ConvTimer()
         ac.ops.timer = voc.ops.timer = timer
         log("warm-up step 2 (all MFMA kernel classes timed)")
@@ -222,8 +247,13 @@ def main():
     for _ in range(max(0, args.warmup - 2)):
         step()
     # ---- timed region: only the dominant class carries event pairs (a few dozen launches per step) ----
-    timer = profiling.ConvTimer(select={dominant}) if dominant else None
-    ac.ops.timer = voc.ops.timer = timer
+    timer = None
+    if use_native:
+        if dominant:
+            pipe.profile(True, dominant)
+    else:
+        timer = profiling.ConvTimer(select={dominant}) if dominant else None
+        ac.ops.timer = voc.ops.timer = timer
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -243,7 +273,15 @@ def main():
         tt = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    ac.ops.timer = voc.ops.timer = None
+    dom_summary = None
+    if use_native:
+        if dominant:
+            dom_summary = pipe.profile_summary()[dominant]
+        pipe.profile(False)
+    else:
+        if dominant:
+            dom_summary = timer.summary()[dominant]
+        ac.ops.timer = voc.ops.timer = None
 
     frames_out = int(sum(m.shape[0] for m in out["mel"]))
     audio_s = frames_out * 384 / 24000.0
@@ -271,7 +309,7 @@ def main():
     if rank == 0:
         roof = None
         if dominant:
-            dom = timer.summary()[dominant]
+            dom = dom_summary
             is16 = ("bf16" in dominant or "f16" in dominant or "resblock" in dominant) and "f32" not in dominant
             peak = PEAK_16BIT_TFLOPS if is16 else PEAK_F32_TFLOPS
             traffic, valu_per_elem, src = committed_counters(dominant)
@@ -310,7 +348,8 @@ def main():
                        "global_batch": world * B, "phones": L, "frames_per_utt": frames_out // B, "vocoder": args.vocoder,
                        "acoustic_dtype": f"{args.dtype} MFMA / f32 activations" if args.dtype != "fp32" else "f32",
                        "vocoder_dtype": args.dtype if args.dtype != "fp32" else "f32", "parallelism": f"dp{world}",
-                       "hip_graphs": bool(args.graphs)},
+                       "hip_graphs": bool(args.graphs),
+                       "sequencer": "native stage API (csrc/pipeline.hip)" if use_native else "python (engine.py)"},
             "acoustic_mel_frames_per_s": world * frames_out * args.steps / t_ac,
             "vocoder_rtf": t_voc / (args.steps * audio_s),
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),

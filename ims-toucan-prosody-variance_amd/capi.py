@@ -111,6 +111,9 @@ PROTOTYPES = {
     "tts_prosody": (C.c_int, [_p, C.POINTER(_p), C.POINTER(_p), C.POINTER(_p)]),
     "tts_copy_mel": (C.c_int, [_p, _p, _i, _p]),
     "tts_copy_prosody": (C.c_int, [_p, _p, _p, _p, _p]),
+    "tts_profile": (C.c_int, [_p, _i, C.c_char_p]),
+    "tts_profile_count": (_i, [_p]),
+    "tts_profile_read": (C.c_int, [_p, _i, C.c_char_p, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tts_vocoder_bigvgan": (C.c_int, [_p, _p, _i, _p, _p, _i, _p, _p]),
     "tts_vocoder_hifigan": (C.c_int, [_p, _p, _i, _p, _p, _i, _p, _p]),
     "tts_synthesize_batch": (C.c_int, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, C.c_int64, C.POINTER(C.c_int64), _p]),

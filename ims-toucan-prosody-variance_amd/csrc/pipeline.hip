@@ -39,7 +39,7 @@ struct ConvW {
   const void* w16 = nullptr;
   const float* bias = nullptr;
   int mode = 0, taps = 1, dil = 1, pad_left = 0, cin = 0, cin_pad = 0, cout = 0, wn = 0, half_pad = 0, tile_rows = 0, small_tile_rows = 0,
-      small_only = 0, n_tile = 0, compute16 = 0;
+      small_only = 0, n_tile = 0, compute16 = 0, algo_taps = 1;
 };
 
 // packed ragged layout: utterance u occupies rows [begins[u], begins[u] + lengths[u])
@@ -92,6 +92,13 @@ struct TileTab {
   int n = 0;
 };
 
+// one timed launch of the roofline leg (tts_profile): HIP events on the launch stream around a matrix-core kernel
+struct ProfRec {
+  std::string name;
+  double flops = 0, bytes = 0, elems = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
 }  // namespace
 
 struct Handle {
@@ -114,6 +121,11 @@ struct Handle {
   float *cat = nullptr, *dec = nullptr, *mel0 = nullptr, *mel = nullptr;
   std::vector<int> frames;  // per utterance, after the control step
   bool have_flow = false;
+  // profiling (bench.py's roofline leg): event pairs around the launches of the selected kernel class ("" = every class)
+  bool prof_on = false;
+  std::string prof_select;
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
 };
 
 namespace {
@@ -261,7 +273,32 @@ int conv_of(const Handle* h, const std::string& name, ConvW* c) {
   c->mode = mm[0]; c->taps = mm[1]; c->dil = mm[2]; c->pad_left = mm[3]; c->cin = mm[4]; c->cin_pad = mm[5]; c->cout = mm[6];
   c->wn = mm[7]; c->half_pad = mm[8]; c->tile_rows = mm[9]; c->small_tile_rows = mm[10]; c->small_only = mm[11]; c->n_tile = mm[12];
   c->compute16 = mm[13];
+  c->algo_taps = mm[14] > 0 ? mm[14] : c->taps;
   return TTS_OK;
+}
+
+// ---- profiling hook ---------------------------------------------------------------------------------------------------------
+hipEvent_t prof_event(Handle* h) {
+  if (!h->event_pool.empty()) {
+    hipEvent_t e = h->event_pool.back();
+    h->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+bool prof_wants(const Handle* h, const std::string& name) { return h->prof_on && (h->prof_select.empty() || h->prof_select == name); }
+
+ProfRec* prof_open(Handle* h, const std::string& name, double flops, double bytes, double elems, hipStream_t st) {
+  h->prof.emplace_back();
+  ProfRec* r = &h->prof.back();
+  r->name = name; r->flops = flops; r->bytes = bytes; r->elems = elems;
+  r->e0 = prof_event(h);
+  r->e1 = prof_event(h);
+  (void)hipEventRecord(r->e0, st);
+  return r;
 }
 
 // ---- one conv launch (engine.Ops.conv) ----------------------------------------------------------------------------------
@@ -317,6 +354,24 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
   d.io_flags = (x.bits == 16 ? TTS_IO_X_BF16 : 0) | (y.bits == 16 ? TTS_IO_Y_BF16 : 0) | ((o.res.p && o.res.bits == 16) ? TTS_IO_RES_BF16 : 0) |
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
+  if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
+    const bool dual = cw.mode != TTS_MODE_LINEAR;
+    const int bm = tile_rows != cw.tile_rows ? tile_rows : cw.tile_rows, bn = tile_rows != cw.tile_rows ? 64 : cw.n_tile;
+    char name[64];
+    snprintf(name, sizeof(name), "conv1d_%s<%dx%d%s>", d.compute == TTS_COMPUTE_F32 ? "f32" : (d.compute == TTS_COMPUTE_BF16 ? "bf16" : "f16"), bm, bn,
+             dual ? ",dual" : "");
+    if (prof_wants(h, name)) {
+      double rows = 0;
+      for (int n : l.lengths) rows += n;
+      const double ctot = (double)cw.cout * (dual ? 2 : 1);
+      ProfRec* r = prof_open(h, name, 2.0 * rows * cw.cin * ctot * cw.algo_taps,
+                             rows * (cw.cin * (x.bits / 8.0) + cw.cout * (y.bits / 8.0)) + cw.taps * cw.cin * ctot * (d.compute == TTS_COMPUTE_F32 ? 4 : 2),
+                             rows * cw.cout, st);
+      const int rc = tts_conv1d(&d, st);
+      (void)hipEventRecord(r->e1, st);
+      return rc;
+    }
+  }
   return tts_conv1d(&d, st);
 }
 
@@ -891,7 +946,18 @@ int pipeline_vocoder(Handle* h, int kind, const float* mel, int ld_mel, const in
           r.alpha1 = a1; r.beta1 = b1; r.alpha2 = a2; r.beta2 = b2; r.filt = filt; r.fir_tab = fir_tab;
           r.alpha = last ? 1.0f / 3.0f : 1.0f; r.res_scale = r.alpha; r.accumulate = (last && j > 0) ? 1 : 0;
           r.io_bf16 = 1; r.tiles = trb.dev; r.n_tiles = trb.n; r.tile_rows = tts_resblock_tile_rows(ch); r.compute = c1.compute16;
-          TTS_TRY(tts_resblock_step(&r, st));
+          char pname[32];
+          snprintf(pname, sizeof(pname), "resblock_step<%d>", ch);
+          if (prof_wants(h, pname)) {
+            double rows = 0;
+            for (int n : l.lengths) rows += n;
+            ProfRec* pr = prof_open(h, pname, 2.0 * rows * ch * ch * c1.taps * 2, 2.0 * rows * ch * se + 2.0 * c1.taps * ch * ch * 2, rows * ch, st);
+            const int rc = tts_resblock_step(&r, st);
+            (void)hipEventRecord(pr->e1, st);
+            if (rc != TTS_OK) return rc;
+          } else {
+            TTS_TRY(tts_resblock_step(&r, st));
+          }
           cur = dst;
           continue;
         }
@@ -979,6 +1045,42 @@ int tts_prosody(TtsHandle* h, const int32_t** durations, const float** pitch, co
   if (durations) *durations = hh->dur;
   if (pitch) *pitch = hh->pitch;
   if (energy) *energy = hh->energy;
+  return TTS_OK;
+}
+int tts_profile(TtsHandle* h, int32_t enable, const char* select) {
+  tts::Handle* hh = H(h);
+  if (!hh) {
+    tts::set_error("tts_profile: null handle");
+    return TTS_E_ARG;
+  }
+  for (auto& r : hh->prof) {
+    hh->event_pool.push_back(r.e0);
+    hh->event_pool.push_back(r.e1);
+  }
+  hh->prof.clear();
+  hh->prof_on = enable != 0;
+  hh->prof_select = select ? select : "";
+  return TTS_OK;
+}
+int32_t tts_profile_count(TtsHandle* h) { return h ? (int32_t)H(h)->prof.size() : 0; }
+int tts_profile_read(TtsHandle* h, int32_t index, char* name, int32_t name_cap, double* ms, double* flops, double* bytes, double* elems) {
+  tts::Handle* hh = H(h);
+  if (!hh || index < 0 || index >= (int32_t)hh->prof.size()) {
+    tts::set_error("tts_profile_read: index %d out of range", index);
+    return TTS_E_ARG;
+  }
+  const tts::ProfRec& r = hh->prof[index];
+  float t = 0.f;
+  const hipError_t e = hipEventSynchronize(r.e1);
+  if (e != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) {
+    tts::set_error("tts_profile_read: event timing failed");
+    return TTS_E_LAUNCH;
+  }
+  if (name && name_cap > 0) snprintf(name, name_cap, "%s", r.name.c_str());
+  if (ms) *ms = t;
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  if (elems) *elems = r.elems;
   return TTS_OK;
 }
 int tts_copy_prosody(TtsHandle* h, int32_t* durations, float* pitch, float* energy, tts_stream_t stream) {

@@ -105,12 +105,23 @@ class ToucanTTSInterface(torch.nn.Module):
         self.use_lang_id = "encoder.language_embedding.weight" in sd
         # precision of the MFMA GEMMs: fp32 (exact-parity default), or TOUCAN_PRECISION=bf16 / f16 (BASELINE.json configs[2] / [4])
         precision = os.environ.get("TOUCAN_PRECISION", "f32")
-        self.phone2mel = engine.AcousticEngine(sd, device, precision=precision)
+        voc = _load_checkpoint(vocoder_model_path)
+        voc_sd, kind = _to_numpy_sd(voc["generator"]), "hifigan" if faster_vocoder else "bigvgan"
+        # On a GPU the whole pass runs through the stage API (native.NativePipeline -> csrc/pipeline.hip: the kernels are sequenced in
+        # C++, a dozen C calls per batch).  TOUCAN_PY_SEQUENCER=1 - and the CPU test emulator - keep engine.py's Python sequencing.
+        import ctypes
+        from . import capi
+        self.pipe = None
+        if torch.device(device).type == "cuda" and isinstance(capi.lib(), ctypes.CDLL) and not os.environ.get("TOUCAN_PY_SEQUENCER"):
+            from . import native
+            self.pipe = native.NativePipeline(sd, voc_sd, kind, device, precision=precision)
+            self.phone2mel = self.mel2wav = self.pipe  # (the reference's attribute names; both stages live in the one handle)
+        else:
+            self.phone2mel = engine.AcousticEngine(sd, device, precision=precision)
+            self.mel2wav = engine.VocoderEngine(voc_sd, kind, device, precision=precision)
 
         self.embedding_model_path = embedding_model_path  # GST network: not on the hot path (see module docstring)
 
-        voc = _load_checkpoint(vocoder_model_path)
-        self.mel2wav = engine.VocoderEngine(_to_numpy_sd(voc["generator"]), "hifigan" if faster_vocoder else "bigvgan", device, precision=precision)
 
         self.default_utterance_embedding = checkpoint["default_emb"].to(self.device)
         self.lang_id = get_language_id_tensor(language) if self.use_lang_id else None
@@ -168,6 +179,10 @@ class ToucanTTSInterface(torch.nn.Module):
         """One ragged batch through both engines.  Returns (packed waveform, [(first sample, sample count)] per utterance)."""
         emb = torch.stack([e.reshape(-1).to(torch.float32).cpu() for e in embs])
         lang_ids = None if any(l is None for l in langs) else langs
+        if self.pipe is not None:
+            out = self.pipe.forward(phones, emb, lang_ids, z_noise=z_noise, **kw)
+            self.last_durations, self.last_pitch, self.last_energy = out["durations"], out["pitch"], out["energy"]
+            return out["wav"], out["wav_spans"]
         out = self.phone2mel.forward(phones, emb, lang_ids, z_noise=z_noise, **kw)
         wav, rag = self.mel2wav.forward(out["mel_packed"], out["rag_mel"])
         self.last_durations, self.last_pitch, self.last_energy = out["durations"], out["pitch"], out["energy"]

@@ -77,7 +77,7 @@ class NativePipeline:
         if cw.bias is not None:
             self._load(name + ".bias", cw.bias)
         meta = [cw.mode, cw.taps, cw.dil, cw.pad_left, cw.cin, cw.cin_pad, cw.cout, cw.wn, cw.half_pad, cw.tile_rows, cw.small_tile_rows,
-                int(cw.small_only), cw.n_tile, cw.compute16, 0, 0]
+                int(cw.small_only), cw.n_tile, cw.compute16, cw.algo_taps, 0]
         self._load(name + ".meta", torch.tensor(meta, dtype=torch.int32))
 
     def _upload_acoustic(self, ac):
@@ -158,6 +158,30 @@ class NativePipeline:
         self._load("pe", torch.from_numpy(packing.rel_pos_encoding(pmax)))
         self._pmax = pmax
 
+    def profile(self, enable, select=None):
+        """Roofline leg: HIP events around the launches of one matrix-core kernel class (None: all) inside the stage entries."""
+        capi.check(self.lib.tts_profile(self.h, 1 if enable else 0, None if select is None else select.encode()), "tts_profile")
+
+    def profile_summary(self):
+        """class -> dict(launches, total_ms, avg_us, flops_per_launch, bytes_per_launch, elems_per_launch, tflops) (waits for the events)."""
+        out = {}
+        name = C.create_string_buffer(64)
+        ms, fl, by, el = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        for i in range(int(self.lib.tts_profile_count(self.h))):
+            capi.check(self.lib.tts_profile_read(self.h, i, name, 64, C.byref(ms), C.byref(fl), C.byref(by), C.byref(el)), "tts_profile_read")
+            s = out.setdefault(name.value.decode(), dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, elems=0.0))
+            s["launches"] += 1
+            s["total_ms"] += ms.value
+            s["flops"] += fl.value
+            s["bytes"] += by.value
+            s["elems"] += el.value
+        for s in out.values():
+            n = s["launches"]
+            s["avg_us"] = 1e3 * s["total_ms"] / n
+            s["flops_per_launch"], s["bytes_per_launch"], s["elems_per_launch"] = s["flops"] / n, s["bytes"] / n, s["elems"] / n
+            s["tflops"] = s["flops"] / (s["total_ms"] * 1e-3) / 1e12 if s["total_ms"] > 0 else 0.0
+        return out
+
     def workspace_bytes(self, B, Lmax, Tmax):
         return int(self.lib.tts_workspace_bytes(self.h, B, Lmax, Tmax))
 
@@ -230,6 +254,36 @@ class NativePipeline:
         if vocode and self.kind is not None:
             out["wav"], out["wav_spans"] = self._vocode_internal(rag_out, st)
         return out
+
+    @torch.inference_mode()
+    def predict_frame_counts(self, texts, utt_embs, lang_ids=None, pitch=None, energy=None, duration_scaling_factor=1.0,
+                             pitch_variance_scale=1.0, energy_variance_scale=1.0, pause_duration_scaling_factor=1.0):
+        """Stage A alone (tts_encoder, tts_variance_predictors, tts_control_and_regulate): mel frames per utterance - the balancing
+        key of the multi-GPU deal (distributed.py)."""
+        with torch.cuda.device(self.device):
+            dev, lib, st = self.device, self.lib, self._stream()
+            B = len(texts)
+            Ls = [int(t.shape[0]) for t in texts]
+            self._ensure_pe(max(Ls))
+            text = torch.cat([t.reshape(-1, 62).to(torch.float32) for t in texts], dim=0).to(dev).contiguous()
+            emb = utt_embs.to(dev, torch.float32).reshape(B, 64).contiguous() if utt_embs is not None else None
+            lang = torch.tensor([int(i) for i in lang_ids], dtype=torch.int32).to(dev) if (self.multilingual and lang_ids is not None) else None
+            cat = lambda lst: None if lst is None else torch.cat([torch.as_tensor(v).reshape(-1).to(torch.float32) for v in lst]).to(dev).contiguous()
+            gp, ge = cat(pitch), cat(energy)
+            ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+            capi.check(lib.tts_encoder(self.h, ptr(text), ptr(emb), ptr(lang), (C.c_int32 * B)(*Ls), B, st), "tts_encoder")
+            capi.check(lib.tts_variance_predictors(self.h, ptr(gp), ptr(ge), None, st), "tts_variance_predictors")
+            frames = (C.c_int32 * B)()
+            capi.check(lib.tts_control_and_regulate(self.h, float(duration_scaling_factor), float(pitch_variance_scale),
+                                                    float(energy_variance_scale), float(pause_duration_scaling_factor), frames, st),
+                       "tts_control_and_regulate")
+            return [int(f) for f in frames]
+
+    @torch.inference_mode()
+    def vocode_batch(self, rag_mel):
+        """Vocoder on the mel of the batch `forward(..., vocode=False)` just produced (it still sits in the handle's workspace)."""
+        with torch.cuda.device(self.device):
+            return self._vocode_internal(rag_mel, self._stream())
 
     def _vocode_internal(self, rag_mel, st):
         """Vocoder on the mel that sits in the handle's workspace (no copy)."""

@@ -267,7 +267,7 @@ int tts_destroy(TtsHandle* h);
  * copied to the device; 3 = int32 host metadata (the descriptor fields of a packed conv, kept on the host).
  * A packed conv "<n>" is the group "<n>.w" [taps][cin_pad][wn] f32, optional "<n>.w16" [taps][cin_pad/8][wn][8], optional
  * "<n>.bias", and "<n>.meta" = int32[16] {mode, taps, dil, pad_left, cin, cin_pad, cout, wn, half_pad, tile_rows,
- * small_tile_rows, small_only, n_tile, compute16, 0, 0} (see tts_conv1d).  Names: INTEGRATION.md lists them; the host packer is
+ * small_tile_rows, small_only, n_tile, compute16, algo_taps, 0} (see tts_conv1d).  Names: INTEGRATION.md lists them; the host packer is
  * ims-toucan-prosody-variance_amd/native.py. */
 int tts_load_weights(TtsHandle* h, const char* name, const void* host_ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
 
@@ -299,6 +299,13 @@ int tts_copy_mel(TtsHandle* h, float* dst, int32_t ld_dst, tts_stream_t stream);
 int tts_prosody(TtsHandle* h, const int32_t** durations, const float** pitch, const float** energy);
 /* The same, copied into caller buffers of sum(phone_lengths) elements each (any of them may be NULL). */
 int tts_copy_prosody(TtsHandle* h, int32_t* durations, float* pitch, float* energy, tts_stream_t stream);
+/* Roofline instrumentation (bench.py): while enabled, every launch of the matrix-core kernel class `select` (NULL / "": every
+ * class; names as in profiling.py: "resblock_step<64>", "conv1d_bf16<128x128>", ...) made by the stage entries is bracketed by
+ * HIP events on the launch stream.  tts_profile(h, ...) also clears earlier records.  tts_profile_read waits for record `index`
+ * and returns its duration and its algorithmic work (FLOPs, bytes of the tensors it reads and writes once + weights, output elements). */
+int tts_profile(TtsHandle* h, int32_t enable, const char* select);
+int32_t tts_profile_count(TtsHandle* h);
+int tts_profile_read(TtsHandle* h, int32_t index, char* name, int32_t name_cap, double* ms, double* flops, double* bytes, double* elems);
 /* mel: packed [rows, 80] with row stride ld_mel; wav: packed, utterance u at 384 * frame_begins[u], 384 * frame_counts[u] samples. */
 int tts_vocoder_bigvgan(TtsHandle* h, const float* mel, int32_t ld_mel, const int32_t* frame_begins /*host*/,
                         const int32_t* frame_counts /*host*/, int32_t B, float* wav, tts_stream_t stream);

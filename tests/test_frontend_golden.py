@@ -34,3 +34,20 @@ def test_frontend_class_returns_the_same_tensor():
 def test_language_ids_match_reference():
     for lang, want in GOLD["language_ids"].items():
         assert phonemes.get_language_id(lang) == want
+
+
+def test_file_reader_harness_phoneme_lines_are_fully_covered_by_the_table(capsys):
+    """run_phoneme_file_reader.py (counterpart of the reference's run_text_to_file_reader.py:8-41) carries the fourteen lines of the poem as phoneme strings:
+    every symbol must be one the articulatory table knows (no "unknown phoneme" diagnostics), one string per text line."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("reader_harness", os.path.join(root, "run_phoneme_file_reader.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert len(mod.THE_RAVEN) == len(mod.THE_RAVEN_PHONES) == 14
+    for line in mod.THE_RAVEN_PHONES:
+        feats = phonemes.phones_to_features(line)
+        assert capsys.readouterr().out == "", line
+        assert 20 < feats.shape[0] < 128 and line.startswith("~") and line.endswith("#")
+        assert feats[-1, phonemes.IDX["end_of_sentence"]] == 1.0

@@ -332,6 +332,28 @@ def test_drop_in_interface_on_the_gpu(tmp_path, monkeypatch):
         assert len(both) == 2 and all(w.is_cuda for w in both)
 
 
+def test_file_reader_harness_end_to_end(tmp_path, monkeypatch):
+    """run_phoneme_file_reader.py (counterpart of the reference's run_text_to_file_reader.py:8-41): the fourteen lines of the poem through the drop-in
+    interface on the GPU (stage API), one ragged batch, into a 24 kHz file with 10 600 samples of silence around every sentence."""
+    import importlib.util
+    import wave
+    from ims_toucan_prosody_variance_amd import interface
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    models = tmp_path / "Models"
+    interface.write_fixture_checkpoints(str(models), n_lang=20)
+    monkeypatch.setattr(interface, "MODELS_DIR", str(models))
+    monkeypatch.chdir(tmp_path)
+    spec = importlib.util.spec_from_file_location("reader_harness", os.path.join(root, "run_phoneme_file_reader.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "have_phonemizer", lambda: False)
+    mod.the_raven(version="test", model_id="Meta", exec_device="cuda", speed_over_quality=True)
+    with wave.open(str(tmp_path / "audios" / "the_raven_test.wav")) as f:
+        assert f.getframerate() == 24000 and f.getnchannels() == 1
+        n = f.getnframes()
+    assert n > 15 * 10600 and (n - 15 * 10600) % 768 == 0  # 14 sentences of an even number of frames, 15 silences
+
+
 def test_native_library_is_the_one_loaded():
     from ims_toucan_prosody_variance_amd import capi
     import ctypes

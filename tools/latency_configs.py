@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 import ims_toucan_prosody_variance_amd  # noqa: F401
-from ims_toucan_prosody_variance_amd import engine, fixture_weights as fw, synthetic as syn
+from ims_toucan_prosody_variance_amd import capi, engine, fixture_weights as fw, native, synthetic as syn
 
 
 def timeit(fn, reps):
@@ -33,33 +33,51 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
-    ap.add_argument("--graphs", action="store_true", help="replay the pass as HIP graphs (fixed shapes)")
+    ap.add_argument("--graphs", action="store_true", help="replay the pass as HIP graphs (fixed shapes; python sequencer)")
+    ap.add_argument("--sequencer", default="native", choices=["native", "python"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, use_graphs=args.graphs)
-    voc = engine.VocoderEngine(fw.hifigan_state_dict(), "hifigan", dev, use_graphs=args.graphs)
+    use_native = args.sequencer == "native" and not args.graphs
+    if use_native:
+        pipe = native.NativePipeline(fw.acoustic_state_dict(), fw.hifigan_state_dict(), "hifigan", dev)
+    else:
+        ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, use_graphs=args.graphs)
+        voc = engine.VocoderEngine(fw.hifigan_state_dict(), "hifigan", dev, use_graphs=args.graphs)
+    tag = "native stage API" if use_native else "python sequencer"
 
     L = 128
     text = [torch.from_numpy(syn.utterance_features(0, L, word_boundaries=False)).to(dev)]
     emb = torch.from_numpy(syn.utterance_embedding(0))[None].to(dev)
     dur = [torch.full((L,), 5, dtype=torch.int32, device=dev)]
     z = [torch.from_numpy(syn.postflow_noise(0, 5 * L)).to(dev)]
-    t = timeit(lambda: ac.forward(text, emb, [syn.LANG_EN], durations=dur, z_noise=z), args.reps)
-    print(json.dumps({"config": "configs[1]: batch=1 x 128 phonemes, acoustic fp32, mel only", "graphs": args.graphs, "ms": 1e3 * t,
-                      "mel_frames_per_s": 5 * L / t}))
+    if use_native:
+        run1 = lambda: pipe.forward(text, emb, [syn.LANG_EN], durations=dur, z_noise=z, vocode=False)
+    else:
+        run1 = lambda: ac.forward(text, emb, [syn.LANG_EN], durations=dur, z_noise=z)
+    c0 = capi.CALLS
+    run1()
+    calls = capi.CALLS - c0
+    t = timeit(run1, args.reps)
+    print(json.dumps({"config": "configs[1]: batch=1 x 128 phonemes, acoustic fp32, mel only", "graphs": args.graphs, "sequencer": tag,
+                      "abi_calls": calls, "ms": 1e3 * t, "mel_frames_per_s": 5 * L / t}))
 
     L = 20
     text = [torch.from_numpy(syn.utterance_features(1, L)).to(dev)]
     emb = torch.from_numpy(syn.utterance_embedding(1))[None].to(dev)
 
     def e2e():
+        if use_native:
+            out = pipe.forward(text, emb, [syn.LANG_EN])
+            b, n = out["wav_spans"][0]
+            return out["wav"][b:b + n]
         out = ac.forward(text, emb, [syn.LANG_EN])
-        return voc.forward(out["mel_packed"], out["rag_mel"])
+        w, rw = voc.forward(out["mel_packed"], out["rag_mel"])
+        return w[: rw.lengths[0]]
 
     t = timeit(e2e, args.reps)
-    wav, _ = e2e()
+    wav = e2e()
     print(json.dumps({"config": "configs[0]-like: one 20-phoneme utterance, predicted durations, acoustic + Avocodo fp32, end to end",
-                      "graphs": args.graphs, "ms": 1e3 * t, "audio_s": wav.numel() / 24000.0, "rtf": t / (wav.numel() / 24000.0)}))
+                      "graphs": args.graphs, "sequencer": tag, "ms": 1e3 * t, "audio_s": wav.numel() / 24000.0, "rtf": t / (wav.numel() / 24000.0)}))
 
 
 if __name__ == "__main__":
