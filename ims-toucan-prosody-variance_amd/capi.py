@@ -96,6 +96,11 @@ PROTOTYPES = {
     "tts_conv_post_snake_tile_rows": (C.c_int, []),
     "tts_conv_post_snake": (C.c_int, [_p, _i, _i, _p, _f, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "tts_gather_rows": (C.c_int, [_p, _i, _p, _p, _i, _i, _i, _p]),
+    # per-speaker path (csrc/style.hip)
+    "tts_gru_layer": (C.c_int, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p]),
+    "tts_style_tokens": (C.c_int, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "tts_complex_magnitude": (C.c_int, [_p, _i, _p, _i, _i, _i, _p]),
+    "tts_log10_floor": (C.c_int, [_p, _i, _p, _i, _i, _i, _f, _p]),
     # stage API (csrc/pipeline.hip)
     "tts_create": (C.c_int, [C.POINTER(TtsConfig), C.POINTER(_p)]),
     "tts_destroy": (C.c_int, [_p]),
@@ -121,7 +126,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 8  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 9  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

@@ -305,3 +305,44 @@ def bigvgan_state_dict(seed: int = 5678) -> dict:
 
 def default_utterance_embedding(seed: int = 2000) -> np.ndarray:
     return normal("default_emb", (UTT,), seed)
+
+
+# --------------------------------------------------------------------------------------
+# style embedding (GST): TrainingInterfaces/Spectrogram_to_Embedding/StyleEmbedding.py, GST.py
+# --------------------------------------------------------------------------------------
+GST_CHANS = (32, 32, 64, 64, 128, 128, 256, 256)
+GST_UNITS, GST_TOKENS, GST_HEADS, GST_DIM = 256, 2000, 8, 64
+
+
+def style_state_dict(seed: int = 8765) -> dict:
+    """Reference-schema state dict of ``StyleEmbedding`` (keys ``gst.ref_enc.*``, ``gst.stl.*``; GST.py:31-57): kaiming-like
+    conv weights, non-trivial BatchNorm running statistics, PyTorch-default GRU / Linear ranges, N(0,1) style tokens."""
+    sd = {}
+    cin = 1
+    for i, c in enumerate(GST_CHANS):
+        p = f"gst.ref_enc.convs.{3 * i}"
+        sd[p + ".weight"] = normal("gst.conv%d" % i, (c, cin, 3, 3), seed, std=float(np.sqrt(2.0 / (cin * 9))))
+        q = f"gst.ref_enc.convs.{3 * i + 1}"
+        sd[q + ".weight"] = normal("gst.bnw%d" % i, (c,), seed, 0.1, 1.0)
+        sd[q + ".bias"] = normal("gst.bnb%d" % i, (c,), seed, 0.1)
+        sd[q + ".running_mean"] = normal("gst.bnm%d" % i, (c,), seed, 0.1)
+        sd[q + ".running_var"] = uniform("gst.bnv%d" % i, (c,), seed, 0.5, 1.5)
+        sd[q + ".num_batches_tracked"] = np.array(100, dtype=np.int64)
+        cin = c
+    k = float(1.0 / np.sqrt(GST_UNITS))
+    for layer in range(2):
+        for nm, shape in (("weight_ih", (3 * GST_UNITS, GST_UNITS)), ("weight_hh", (3 * GST_UNITS, GST_UNITS)), ("bias_ih", (3 * GST_UNITS,)),
+                          ("bias_hh", (3 * GST_UNITS,))):
+            sd[f"gst.ref_enc.gst.{nm}_l{layer}"] = uniform(f"gst.gru.{nm}{layer}", shape, seed, -k, k)
+    sd["gst.stl.gst_embs"] = normal("gst.tokens", (GST_TOKENS, GST_DIM // GST_HEADS), seed)
+    for nm, (o, i) in (("linear_q", (GST_DIM, GST_UNITS)), ("linear_k", (GST_DIM, GST_DIM // GST_HEADS)), ("linear_v", (GST_DIM, GST_DIM // GST_HEADS)),
+                       ("linear_out", (GST_DIM, GST_DIM))):
+        b = float(1.0 / np.sqrt(i))
+        sd[f"gst.stl.mha.{nm}.weight"] = uniform("gst." + nm, (o, i), seed, -b, b)
+        sd[f"gst.stl.mha.{nm}.bias"] = uniform("gst." + nm + "b", (o,), seed, -b, b)
+    return sd
+
+
+def reference_spectrogram(u: int, frames: int) -> np.ndarray:
+    """Seeded stand-in for a log-mel spectrogram [frames, 80] (values in the range log10 mel energies take)."""
+    return (normal(f"spec{u}", (frames, N_MEL), 7000 + u, 0.8) - np.float32(2.0)).astype(np.float32)

@@ -11,8 +11,10 @@ script written against the reference (run_text_to_file_reader.py:8-16) works unc
   strings skipped, 24 kHz output or sample-doubled 48 kHz PCM16), ``read_aloud`` (:287-309), the language / embedding setters
 * additive API: ``synthesize_batch`` (ragged batches, optionally sharded over the ranks of torch.distributed)
 
-What is NOT here (outside the hot path, unavailable offline): grapheme-to-phoneme conversion (espeak-ng),
-the GST style-embedding network behind ``set_utterance_embedding(path)``, plotting.  These raise explicit errors.
+* ``set_utterance_embedding(path)`` (:103-114): reference audio -> log-mel -> GST style embedding on the GPU (style.py)
+
+What is NOT here (unavailable offline): grapheme-to-phoneme conversion needs espeak-ng / phonemizer (raw text
+raises unless that package is importable), the silero voice-activity trim of the reference audio, plotting.
 """
 import os
 import wave as _wave
@@ -76,9 +78,10 @@ def write_fixture_checkpoints(models_dir=MODELS_DIR, n_lang=8000):
     for sub, obj in (("ToucanTTS_Meta", {"model": t(fw.acoustic_state_dict(n_lang=n_lang)),
                                          "default_emb": torch.from_numpy(fw.default_utterance_embedding())}),
                      ("Avocodo", {"generator": t(fw.hifigan_state_dict())}),
-                     ("BigVGAN", {"generator": t(fw.bigvgan_state_dict())})):
+                     ("BigVGAN", {"generator": t(fw.bigvgan_state_dict())}),
+                     ("Embedding", {"style_emb_func": t(fw.style_state_dict())})):
         os.makedirs(os.path.join(models_dir, sub), exist_ok=True)
-        torch.save(obj, os.path.join(models_dir, sub, "best.pt"))
+        torch.save(obj, os.path.join(models_dir, sub, "embedding_function.pt" if sub == "Embedding" else "best.pt"))
 
 
 class ToucanTTSInterface(torch.nn.Module):
@@ -120,7 +123,8 @@ class ToucanTTSInterface(torch.nn.Module):
             self.phone2mel = engine.AcousticEngine(sd, device, precision=precision)
             self.mel2wav = engine.VocoderEngine(voc_sd, kind, device, precision=precision)
 
-        self.embedding_model_path = embedding_model_path  # GST network: not on the hot path (see module docstring)
+        self.embedding_model_path = embedding_model_path  # GST network: loaded on the first set_utterance_embedding(path)
+        self._style = None
 
 
         self.default_utterance_embedding = checkpoint["default_emb"].to(self.device)
@@ -133,8 +137,16 @@ class ToucanTTSInterface(torch.nn.Module):
             self.default_utterance_embedding = embedding.squeeze().to(self.device)
             return
         assert os.path.exists(path_to_reference_audio)
-        raise NotImplementedError("computing a style embedding from audio needs the GST network and the librosa front-end "
-                                  "(outside the MI355X hot path); pass embedding=<tensor[64]> instead")
+        # reference audio -> mono, peak-normalised, 16 kHz -> log-mel -> GST style embedding, the last two on the GPU (style.py).
+        # Deviation (network-only dependency): the reference also trims leading / trailing silence with the silero VAD.
+        from . import style
+        if self._style is None:
+            path = self.embedding_model_path or os.path.join(MODELS_DIR, "Embedding", "embedding_function.pt")  # :71-77
+            self._style = (style.LogMel(self.device), style.StyleEngine(_to_numpy_sd(_load_checkpoint(path)["style_emb_func"]), self.device))
+        data, sr = style.read_audio(path_to_reference_audio)
+        logmel, gst = self._style
+        spec = logmel.forward(style.normalize_reference_audio(data, sr))
+        self.default_utterance_embedding = gst.forward([spec])[0].to(self.device)
 
     def set_language(self, lang_id):
         self.set_phonemizer_language(lang_id=lang_id)
@@ -226,6 +238,28 @@ class ToucanTTSInterface(torch.nn.Module):
                                       durations=rep(durations), pitch=rep(pitch), energy=rep(energy), z_noise=z_noise)
         m = min(w.numel() for w in waves)
         return torch.stack([w[:m] for w in waves]).mean(dim=0)
+
+    def stream(self, text, input_is_phones=False, chunk_frames=512, halo_frames=None, max_batch=4, z_noise=None, **prosody):
+        """Generator of waveform pieces for ONE (long) text: the acoustic model runs once, the vocoder chunk-wise with overlap
+        (streaming.py) - the concatenation equals ``self(text, ...)`` bit for bit, the first piece is ready after one chunk and the
+        vocoder's workspace is bounded by ``max_batch`` chunks.  prosody: the keyword arguments of ``forward`` (gold durations /
+        pitch / energy, scaling factors)."""
+        from . import streaming
+        halo = streaming.DEFAULT_HALO if halo_frames is None else halo_frames
+        listed = {k: [v] for k, v in prosody.items() if k in ("durations", "pitch", "energy") and v is not None}
+        scales = {k: v for k, v in prosody.items() if k.endswith("_factor") or k.endswith("_scale")}
+        with torch.inference_mode():
+            phones = self.text2phone.string_to_tensor(text, input_phonemes=input_is_phones)
+            emb = self.default_utterance_embedding.reshape(1, -1).to(torch.float32).cpu()
+            langs = None if self.lang_id is None else [self._lang()]
+            if self.pipe is not None:
+                out = self.pipe.forward([phones], emb, langs, z_noise=None if z_noise is None else [z_noise], vocode=False, **listed, **scales)
+                vocode = self.pipe.vocode
+            else:
+                out = self.phone2mel.forward([phones], emb, langs, z_noise=None if z_noise is None else [z_noise], **listed, **scales)
+                vocode = self.mel2wav.forward
+            self.last_durations, self.last_pitch, self.last_energy = out["durations"], out["pitch"], out["energy"]
+            yield from streaming.stream_vocode(vocode, out["mel"][0].contiguous(), chunk_frames, halo, max_batch)
 
     SILENCE_SAMPLES = 10600   # between sentences in read_to_file (ToucanTTSInterface.py:267)
     MAX_FILE_BATCH = 32       # sentences synthesised per ragged batch by read_to_file

@@ -235,6 +235,24 @@ int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz,
 int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst, int32_t n,
                     int32_t c, tts_stream_t stream);
 
+/* ---- per-speaker path: GST style embedding and log-mel front end (set_utterance_embedding(path), ToucanTTSInterface.py:103-114) ----
+ * The Conv2d stack (as banded 2-tap convs), the projections, the windowed DFT and the mel projection run through tts_conv1d
+ * (ims-toucan-prosody-variance_amd/style.py packs them); these four entries are the rest. */
+
+/* One layer of torch.nn.GRU (batch_first, zero initial state) over `batch` sequences of `steps` rows: x [batch*steps, in_dim] -> y
+ * [batch*steps, hidden] (all hidden states).  Weights transposed: w_ih_t [in_dim][3*hidden], w_hh_t [hidden][3*hidden], gate order
+ * r, z, n.  hidden <= 256.  TrainingInterfaces/Spectrogram_to_Embedding/GST.py:141,158 (ReferenceEncoder.gst). */
+int tts_gru_layer(const float* x, int32_t ldx, int32_t batch, int32_t steps, int32_t in_dim, int32_t hidden, const float* w_ih_t,
+                  const float* w_hh_t, const float* b_ih, const float* b_hh, float* y, int32_t ldy, tts_stream_t stream);
+/* Style-token attention, one query per utterance: ctx[b, h] = softmax_n(q[b,h] . k[n,h] / sqrt(dk)) v[n,h].  q [batch, heads*dk]
+ * (projected), k / v [n_tokens, heads*dk] (projected tanh(tokens)), dk <= 8.  GST.py:205-219, Layers/Attention.py:66-92. */
+int tts_style_tokens(const float* q, const float* k, const float* v, int32_t batch, int32_t n_tokens, int32_t heads, int32_t dk, float* ctx,
+                     tts_stream_t stream);
+/* y[r, c] = |x[r, c] + i x[r, bins + c]|: magnitude of a spectrum stored as [re | im].  AudioPreprocessor.py:109-110 (np.abs(stft)). */
+int tts_complex_magnitude(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t rows, int32_t bins, tts_stream_t stream);
+/* y = log10(max(eps, x)).  AudioPreprocessor.py:117. */
+int tts_log10_floor(const float* x, int32_t ldx, float* y, int32_t ldy, int32_t rows, int32_t c, float eps, tts_stream_t stream);
+
 /* =====================================================================================================================
  * Stage API: a handle that owns the packed weights and the workspace, and one call per stage of the reference's forward pass
  * (csrc/pipeline.hip sequences the kernels above in C++).  One handle per (process, device); calls on a
@@ -321,7 +339,7 @@ int tts_synthesize_batch(TtsHandle* h, const float* text, const float* utt_emb, 
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 8
+#define TTS_ABI_VERSION 9
 int tts_abi_version(void);
 
 #ifdef __cplusplus

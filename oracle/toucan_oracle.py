@@ -434,3 +434,104 @@ class VocoderOracle:
             x = F.leaky_relu(x, 0.01)  # InferenceAvocodo.py:53 (torch default slope)
         x = torch.tanh(F.conv1d(x, sd[post + ".weight"], sd[post + ".bias"], padding=3))
         return x.reshape(-1)
+
+
+# --------------------------------------------------------------------------------------
+# Style embedding (GST) and the log-mel front end behind set_utterance_embedding(path)
+# (ToucanTTSInterface.py:103-114)
+# --------------------------------------------------------------------------------------
+class StyleOracle:
+    """StyleEmbedding.forward (StyleEmbedding.py:21-57) + StyleEncoder / ReferenceEncoder / StyleTokenLayer (GST.py:59-243)."""
+
+    def __init__(self, state_dict):
+        self.sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(v)) for k, v in state_dict.items()}
+
+    @staticmethod
+    def tile_to_812(spec):
+        """StyleEmbedding.py:40-52: repeat the spectrogram (at least once) until it has 812 frames, keep the first 812."""
+        spec = spec.repeat((2, 1))
+        while len(spec) < 812:
+            spec = spec.repeat((2, 1))
+        return spec[:812]
+
+    def reference_encoder(self, spec):
+        """GST.py:144-161: 8 x (Conv2d k3 s2 p1 no bias, BatchNorm2d eval, ReLU) on [1, 1, 812, 80], then a 2-layer GRU over the
+        remaining time steps; the last hidden state of the top layer is the reference embedding."""
+        sd = self.sd
+        h = spec[None, None]
+        for i in range(8):
+            p, q = f"gst.ref_enc.convs.{3 * i}", f"gst.ref_enc.convs.{3 * i + 1}"
+            h = F.conv2d(h, sd[p + ".weight"], None, stride=2, padding=1)
+            h = F.batch_norm(h, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.0, 1e-5)
+            h = torch.relu(h)
+        hs = h.transpose(1, 2).contiguous().view(1, h.shape[2], -1)[0]  # [T', C * F']
+        x = hs
+        for layer in range(2):  # torch.nn.GRU equations, gate order r, z, n
+            w_ih, w_hh = sd[f"gst.ref_enc.gst.weight_ih_l{layer}"], sd[f"gst.ref_enc.gst.weight_hh_l{layer}"]
+            b_ih, b_hh = sd[f"gst.ref_enc.gst.bias_ih_l{layer}"], sd[f"gst.ref_enc.gst.bias_hh_l{layer}"]
+            hdim = w_hh.shape[1]
+            hcur = torch.zeros(hdim)
+            outs = []
+            for t in range(x.shape[0]):
+                gi, gh = w_ih @ x[t] + b_ih, w_hh @ hcur + b_hh
+                r = torch.sigmoid(gi[:hdim] + gh[:hdim])
+                z = torch.sigmoid(gi[hdim:2 * hdim] + gh[hdim:2 * hdim])
+                n = torch.tanh(gi[2 * hdim:] + r * gh[2 * hdim:])
+                hcur = (1 - z) * n + z * hcur
+                outs.append(hcur)
+            x = torch.stack(outs)
+        return x[-1]
+
+    def style_tokens(self, ref):
+        """GST.py:205-219 + Layers/Attention.py:42-92: one query (the reference embedding) over tanh(2000 style tokens), 8 heads of 8."""
+        sd = self.sd
+        m = "gst.stl.mha."
+        toks = torch.tanh(sd["gst.stl.gst_embs"])
+        q = (sd[m + "linear_q.weight"] @ ref + sd[m + "linear_q.bias"]).view(8, 8)
+        k = (toks @ sd[m + "linear_k.weight"].t() + sd[m + "linear_k.bias"]).view(-1, 8, 8)
+        v = (toks @ sd[m + "linear_v.weight"].t() + sd[m + "linear_v.bias"]).view(-1, 8, 8)
+        scores = torch.einsum("hd,nhd->hn", q, k) / math.sqrt(8)
+        ctx = torch.einsum("hn,nhd->hd", torch.softmax(scores, dim=-1), v).reshape(-1)
+        return sd[m + "linear_out.weight"] @ ctx + sd[m + "linear_out.bias"]
+
+    def __call__(self, spec, return_ref=False):
+        ref = self.reference_encoder(self.tile_to_812(spec))
+        return (self.style_tokens(ref), ref) if return_ref else self.style_tokens(ref)
+
+
+def mel_filterbank(sr=16000, n_fft=1024, n_mels=80, fmin=40.0, fmax=8000.0):
+    """librosa.filters.mel with its defaults (Slaney scale, htk=False, norm='slaney') restated in numpy float64.  Third party
+    (librosa is neither vendored nor installed): PARITY UNPINNED, restated from the package's documented algorithm -
+    linear below 1 kHz (200/3 Hz per mel), logarithmic above (step log(6.4)/27), triangles normalised to constant area."""
+    import numpy as np
+
+    def hz_to_mel(f):
+        f = np.asarray(f, dtype=np.float64)
+        lin = f / (200.0 / 3)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-10) / 1000.0) / (np.log(6.4) / 27.0), lin)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, dtype=np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), m * (200.0 / 3))
+
+    fft_f = np.linspace(0.0, sr / 2.0, n_fft // 2 + 1)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fft_f[None, :]
+    w = np.maximum(0.0, np.minimum(-ramps[:-2] / fdiff[:-1, None], ramps[2:] / fdiff[1:, None]))
+    return (w * (2.0 / (mel_f[2:] - mel_f[:-2]))[:, None]).astype(np.float32)  # [n_mels, n_fft/2 + 1], float32 like librosa
+
+
+def logmel(audio, sr=16000, n_fft=1024, hop=256, n_mels=80, fmin=40.0, fmax=8000.0, eps=1e-10):
+    """AudioPreprocessor.logmelfilterbank (AudioPreprocessor.py:96-117): librosa.stft(n_fft 1024, hop 256, hann, centred with
+    reflect padding) -> magnitude -> mel basis -> log10(max(eps, .)); returns [frames, n_mels] (the reference returns the transpose).
+    float64 numpy restatement; the librosa pieces are PARITY UNPINNED (see mel_filterbank)."""
+    import numpy as np
+    x = np.asarray(audio, dtype=np.float64)
+    x = np.pad(x, n_fft // 2, mode="reflect")
+    n = np.arange(n_fft)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)  # scipy.signal.get_window("hann", n_fft, fftbins=True)
+    frames = 1 + (len(x) - n_fft) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(frames)[:, None]
+    spec = np.abs(np.fft.rfft(x[idx] * win[None, :], axis=1))
+    return np.log10(np.maximum(eps, spec @ mel_filterbank(sr, n_fft, n_mels, fmin, fmax).astype(np.float64).T)).astype(np.float32)

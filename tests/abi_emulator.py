@@ -252,6 +252,49 @@ class Emulator:
             _store(d.y, sb, se, C_, d.ldy, v.astype(np.float32), io)
         return 0
 
+    # ---- per-speaker path (csrc/style.hip) -------------------------------------------------------------------
+    def tts_gru_layer(self, x, ldx, batch, steps, in_dim, hidden, w_ih_t, w_hh_t, b_ih, b_hh, y, ldy, stream):
+        self._count("gru_layer")
+        X = _mat(x, batch * steps, in_dim, ldx).astype(np.float64)
+        Wi = _arr(w_ih_t, in_dim * 3 * hidden).reshape(in_dim, 3 * hidden).astype(np.float64)
+        Wh = _arr(w_hh_t, hidden * 3 * hidden).reshape(hidden, 3 * hidden).astype(np.float64)
+        bi, bh = _arr(b_ih, 3 * hidden).astype(np.float64), _arr(b_hh, 3 * hidden).astype(np.float64)
+        Y = _mat(y, batch * steps, hidden, ldy)
+        H = hidden
+        sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+        for b in range(batch):
+            h = np.zeros(H)
+            for t in range(steps):
+                gi, gh = X[b * steps + t] @ Wi + bi, h @ Wh + bh
+                r, z = sig(gi[:H] + gh[:H]), sig(gi[H:2 * H] + gh[H:2 * H])
+                n = np.tanh(gi[2 * H:] + r * gh[2 * H:])
+                h = (1 - z) * n + z * h
+                Y[b * steps + t] = h.astype(np.float32)
+        return 0
+
+    def tts_style_tokens(self, q, k, v, batch, n_tokens, heads, dk, ctx, stream):
+        self._count("style_tokens")
+        ld = heads * dk
+        Q = _mat(q, batch, ld, ld).astype(np.float64).reshape(batch, heads, dk)
+        K = _mat(k, n_tokens, ld, ld).astype(np.float64).reshape(n_tokens, heads, dk)
+        V = _mat(v, n_tokens, ld, ld).astype(np.float64).reshape(n_tokens, heads, dk)
+        s = np.einsum("bhd,nhd->bhn", Q, K) / math.sqrt(dk)
+        p = np.exp(s - s.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        _mat(ctx, batch, ld, ld)[:] = np.einsum("bhn,nhd->bhd", p, V).reshape(batch, ld).astype(np.float32)
+        return 0
+
+    def tts_complex_magnitude(self, x, ldx, y, ldy, rows, bins, stream):
+        self._count("complex_magnitude")
+        X = _mat(x, rows, 2 * bins, ldx).astype(np.float64)
+        _mat(y, rows, bins, ldy)[:] = np.sqrt(X[:, :bins] ** 2 + X[:, bins:] ** 2).astype(np.float32)
+        return 0
+
+    def tts_log10_floor(self, x, ldx, y, ldy, rows, c, eps, stream):
+        self._count("log10_floor")
+        _mat(y, rows, c, ldy)[:] = np.log10(np.maximum(np.float32(eps), _mat(x, rows, c, ldx))).astype(np.float32)
+        return 0
+
     def tts_layernorm(self, x, ldx, y, ldy, gamma, beta, rows, c, eps, stream):
         self._count("layernorm")
         X = _mat(x, rows, c, ldx).astype(np.float64)

@@ -332,6 +332,48 @@ def test_drop_in_interface_on_the_gpu(tmp_path, monkeypatch):
         assert len(both) == 2 and all(w.is_cuda for w in both)
 
 
+@pytest.mark.parametrize("kind", ["hifigan", "bigvgan"])
+def test_chunked_vocoder_is_bit_identical_on_a_long_utterance(kind):
+    """Overlap-save vocoding (streaming.py): 5 120 frames (1 024 phonemes x 5, tools/long_utterance_check.py's case) cut into
+    512-frame chunks with the default 24-frame halo == the whole mel vocoded at once, bit for bit, in fp32 and in the bf16
+    configuration with fused residual steps - through both sequencers.  A halo below the stack's reach must NOT be identical
+    (the test would be vacuous otherwise)."""
+    from ims_toucan_prosody_variance_amd import native, streaming
+    T = 5120
+    mel = (torch.from_numpy(syn.postflow_noise(77, T)).t().contiguous() * 2.0).to(DEV)  # any mel-shaped signal will do
+    sd = fw.hifigan_state_dict() if kind == "hifigan" else fw.bigvgan_state_dict()
+    for precision in ("f32", "bf16"):
+        voc = engine.VocoderEngine(sd, kind, DEV, precision=precision)
+        whole, rw = voc.forward(mel, Ragged([T], DEV))
+        whole = whole[: rw.lengths[0]]
+        pieces = list(streaming.stream_vocode(voc.forward, mel, chunk_frames=512, max_batch=4))
+        assert len(pieces) == 10 and all(p.numel() == 512 * 384 for p in pieces)
+        assert torch.equal(torch.cat(pieces), whole), (kind, precision)
+        short = streaming.chunked_vocode(voc.forward, mel, chunk_frames=512, halo_frames=4)
+        assert short.shape == whole.shape and not torch.equal(short, whole)
+    pipe = native.NativePipeline(fw.acoustic_state_dict(), sd, kind, DEV)
+    w2 = streaming.chunked_vocode(pipe.vocode, mel, chunk_frames=640, max_batch=3)  # ragged last chunk, another batch size
+    ref, rr = engine.VocoderEngine(sd, kind, DEV).forward(mel, Ragged([T], DEV))
+    assert torch.equal(w2, ref[: rr.lengths[0]])
+    assert streaming.REACH_FRAMES <= streaming.DEFAULT_HALO
+
+
+def test_interface_stream_equals_one_shot_call(tmp_path, monkeypatch):
+    from ims_toucan_prosody_variance_amd import interface
+    models = tmp_path / "Models"
+    interface.write_fixture_checkpoints(str(models), n_lang=20)
+    monkeypatch.setattr(interface, "MODELS_DIR", str(models))
+    tts = interface.ToucanTTSInterface(device="cuda", tts_model_path="Meta", faster_vocoder=False)
+    phones = "~" + "wˈʌns əpˈɑːn ɐ mˈɪdnaɪt dɹˈɪɹi " * 6 + "~#"
+    L = int(tts.text2phone.string_to_tensor(phones, input_phonemes=True).shape[0])
+    dur = torch.full((L,), 6, dtype=torch.long)
+    z = torch.randn(80, 6 * L, generator=torch.Generator().manual_seed(3)) * 0.8
+    pieces = list(tts.stream(phones, input_is_phones=True, chunk_frames=128, durations=dur, z_noise=z))
+    assert len(pieces) > 3
+    one = tts.synthesize_batch([phones], durations=[dur], z_noise=[z])[0]
+    assert torch.equal(torch.cat(pieces), one)
+
+
 def test_file_reader_harness_end_to_end(tmp_path, monkeypatch):
     """run_phoneme_file_reader.py (counterpart of the reference's run_text_to_file_reader.py:8-41): the fourteen lines of the poem through the drop-in
     interface on the GPU (stage API), one ragged batch, into a 24 kHz file with 10 600 samples of silence around every sentence."""
