@@ -122,7 +122,6 @@ PROTOTYPES = {
     "tts_vocoder_bigvgan": (C.c_int, [_p, _p, _i, _p, _p, _i, _p, _p]),
     "tts_vocoder_hifigan": (C.c_int, [_p, _p, _i, _p, _p, _i, _p, _p]),
     "tts_synthesize_batch": (C.c_int, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _f, _f, _f, _f, _p, _p, _p, _p, C.c_int64, C.POINTER(C.c_int64), _p]),
-    "tts_axpby": (C.c_int, [_p, _i, _f, _p, _i, _f, _p, _i, _i, _i, _p]),
 }
 
 _LIB = None

@@ -31,7 +31,6 @@ int l2_normalize(const float*, float*, int, int, hipStream_t);
 int groupnorm(const float*, int, float*, int, const float*, const float*, int, int, float, int, const float*, int, const int*,
               const int*, int, int, float*, hipStream_t);
 long groupnorm_workspace_floats(int, int, int);
-int axpby(const float*, int, float, const float*, int, float, float*, int, int, int, hipStream_t);
 int relpos_attention(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
                      int, hipStream_t);
 int relpos_attention_mfma(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
@@ -170,9 +169,5 @@ int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float*
   return tts::gather_rows(src, ld_src, idx, dst, ld_dst, n, c, ST(stream));
 }
 
-int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz, float b, float* y, int32_t ldy, int32_t rows, int32_t c,
-              tts_stream_t stream) {
-  return tts::axpby(x, ldx, a, z, ldz, b, y, ldy, rows, c, ST(stream));
-}
 
 }  // extern "C"

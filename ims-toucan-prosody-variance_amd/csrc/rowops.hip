@@ -165,16 +165,6 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, int ldx, float a, const float* __restrict__ z,
-                                                    int ldz, float b, float* __restrict__ y, int ldy, int rows, int c) {
-  const size_t n = (size_t)rows * c;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const int r = (int)(i / c), ch = (int)(i % c);
-    float v = a * x[(size_t)r * ldx + ch];
-    if (z) v += b * z[(size_t)r * ldz + ch];
-    y[(size_t)r * ldy + ch] = v;
-  }
-}
 
 __global__ __launch_bounds__(64) void gather_rows_kernel(const float* __restrict__ src, int ld_src, const int* __restrict__ idx,
                                                          float* __restrict__ dst, int ld_dst, int c) {
@@ -281,13 +271,5 @@ long groupnorm_workspace_floats(int n_seq, int max_len, int groups) {
   return (long)n_seq * ((max_len + GN_CHUNK - 1) / GN_CHUNK) * groups * 2;
 }
 
-int axpby(const float* x, int ldx, float a, const float* z, int ldz, float b, float* y, int ldy, int rows, int c, hipStream_t st) {
-  if (rows == 0 || c == 0) return TTS_OK;
-  size_t n = (size_t)rows * c;
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(axpby_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, a, z, ldz, b, y, ldy, rows, c);
-  return launch_status("axpby");
-}
 
 }  // namespace tts

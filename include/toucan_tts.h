@@ -227,10 +227,6 @@ int tts_conv_post_snake(const float* x, int32_t ldx, int32_t cin, const float* w
                         const float* beta, const float* filt /*[12]*/, float* wav, const TtsTile* tiles, int32_t n_tiles,
                         int32_t tile_rows, int32_t io_flags /* TTS_IO_X_BF16 | TTS_IO_F16 */, tts_stream_t stream);
 
-/* Elementwise helper: y = a*x + b*z (z may be NULL), rows x c with strides. */
-int tts_axpby(const float* x, int32_t ldx, float a, const float* z, int32_t ldz, float b, float* y, int32_t ldy,
-              int32_t rows, int32_t c, tts_stream_t stream);
-
 /* dst[i,:] = src[idx[i],:] (embedding lookup, Conformer.py:112-114 language_embedding). */
 int tts_gather_rows(const float* src, int32_t ld_src, const int32_t* idx, float* dst, int32_t ld_dst, int32_t n,
                     int32_t c, tts_stream_t stream);

@@ -504,13 +504,6 @@ class Emulator:
         _mat(dst, n, c, ld_dst)[:] = S[ii]
         return 0
 
-    def tts_axpby(self, x, ldx, a, z, ldz, b, y, ldy, rows, c, stream):
-        self._count("axpby")
-        v = np.float32(a) * _mat(x, rows, c, ldx)
-        if z:
-            v = v + np.float32(b) * _mat(z, rows, c, ldz)
-        _mat(y, rows, c, ldy)[:] = v
-        return 0
 
 
 def install(monkeypatch=None):
