@@ -168,8 +168,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     const int nt = d.taps - tap < TPS ? d.taps - tap : TPS;
     return nt * (TAPW / 8);
   };
+#ifdef RB_DIAG_NO_WLOAD  // (timing diagnostics only: weight slabs are fetched once, results are wrong)
+#define load_slab(step_) do { if ((step_) == 0) wreg.load(slab_src(step_), tid, slab_units(step_)); } while (0)
+#define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * slab_alloc, tid)
+#else
 #define load_slab(step_) wreg.load(slab_src(step_), tid, slab_units(step_))
 #define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * slab_alloc, tid)
+#endif
   load_slab(0);
   store_slab(0);
 

@@ -74,8 +74,8 @@ def test_vocoder_oracle_matches_reference_golden(vocoders, kind, name):
 
 def test_all_goldens_present_and_summarised():
     files = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    # (V20_*: checkpoint variants, tests/test_checkpoint_variants.py)
-    assert files == sorted(n + ".npz" for n in SMALL + ["L128_gold5", "R128", "R97", "R64", "V20_monolingual", "V20_single"])
+    # (V20_*: checkpoint variants, tests/test_checkpoint_variants.py; style: GST embedding, tests/test_style_embedding.py)
+    assert files == sorted(n + ".npz" for n in SMALL + ["L128_gold5", "R128", "R97", "R64", "V20_monolingual", "V20_single", "style"])
     with open(os.path.join(GOLDEN, "SUMMARY.json")) as f:
         s = json.load(f)
     assert s["L128_gold5"]["L"] == 128
