@@ -61,6 +61,19 @@ class TtsResblockDesc(C.Structure):
     ]
 
 
+class TtsWavenetDesc(C.Structure):
+    _fields_ = [
+        ("hs_in", _p), ("ld_in", _i),
+        ("hs_out", _p), ("ld_out", _i),
+        ("cond", _p), ("ld_cond", _i),
+        ("w1", _p), ("b1", _p),
+        ("w2", _p), ("b2", _p),
+        ("cout2", _i),
+        ("compute", _i),
+        ("tiles", _p), ("n_tiles", _i), ("tile_rows", _i),
+    ]
+
+
 class TtsConfig(C.Structure):
     _fields_ = [("multilingual", _i), ("multispeaker", _i), ("vocoder", _i), ("precision", _i), ("small_tile_blocks", _i), ("post_bias", _f)]
 
@@ -78,6 +91,7 @@ PROTOTYPES = {
     "tts_resblock_step": (C.c_int, [C.POINTER(TtsResblockDesc), _p]),
     "tts_resblock_tile_rows": (C.c_int, [_i]),
     "tts_snake_fir_table": (C.c_int, [_p, _p]),
+    "tts_wavenet_layer": (C.c_int, [C.POINTER(TtsWavenetDesc), _p]),
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     "tts_cln_mlp_weight_floats": (C.c_int64, [_i, _i]),
@@ -125,7 +139,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 9  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 10  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

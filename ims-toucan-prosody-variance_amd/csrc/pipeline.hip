@@ -14,6 +14,7 @@
 // Host work here is layout arithmetic (tile tables, offsets) and launch ordering; every FLOP is in the kernels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -109,6 +110,7 @@ struct Handle {
   std::unordered_map<std::string, TileTab> tile_cache;
   std::unordered_map<std::string, int*> bounds_cache;
   int small_tile_blocks = 1536;
+  bool no_fused_wavenet = false;  // TOUCAN_NO_FUSED_WAVENET: A/B switch, same meaning as in engine.py
   // relative position tables [block][2 pmax - 1][192] of the two Conformer stacks, built from the uploaded sinusoid table
   float* ptab[2] = {nullptr, nullptr};
   int pmax = 0;
@@ -122,7 +124,7 @@ struct Handle {
   std::vector<int> frames;  // per utterance, after the control step
   bool have_flow = false;
   // profiling (bench.py's roofline leg): event pairs around the launches of the selected kernel class ("" = every class)
-  bool prof_on = false;
+  bool prof_on = false, prof_detail = false;
   std::string prof_select;
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
@@ -357,9 +359,11 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
     const bool dual = cw.mode != TTS_MODE_LINEAR;
     const int bm = tile_rows != cw.tile_rows ? tile_rows : cw.tile_rows, bn = tile_rows != cw.tile_rows ? 64 : cw.n_tile;
-    char name[64];
-    snprintf(name, sizeof(name), "conv1d_%s<%dx%d%s>", d.compute == TTS_COMPUTE_F32 ? "f32" : (d.compute == TTS_COMPUTE_BF16 ? "bf16" : "f16"), bm, bn,
-             dual ? ",dual" : "");
+    char name[96];
+    int nlen = snprintf(name, sizeof(name), "conv1d_%s<%dx%d%s>", d.compute == TTS_COMPUTE_F32 ? "f32" : (d.compute == TTS_COMPUTE_BF16 ? "bf16" : "f16"),
+                        bm, bn, dual ? ",dual" : "");
+    if (h->prof_detail)  // per-shape classes (tools/conv_shapes.py): where the small-GEMM time goes
+      snprintf(name + nlen, sizeof(name) - nlen, "[%dx%d k%d r%d]", cw.cin, cw.cout * (dual ? 2 : 1), cw.taps, l.total);
     if (prof_wants(h, name)) {
       double rows = 0;
       for (int n : l.lengths) rows += n;
@@ -527,6 +531,7 @@ int pipeline_create(const TtsConfig* cfg, Handle** out) {
   Handle* h = new Handle();
   h->cfg = *cfg;
   if (cfg->small_tile_blocks > 0) h->small_tile_blocks = cfg->small_tile_blocks;
+  h->no_fused_wavenet = getenv("TOUCAN_NO_FUSED_WAVENET") != nullptr;
   *out = h;
   return TTS_OK;
 }
@@ -584,7 +589,7 @@ long long pipeline_workspace_bytes(const Handle* h, int B, int Lmax, int Tmax) {
   if (!h || B <= 0) return 0;
   const size_t RP = (size_t)B * Lmax, RF = (size_t)B * (Tmax + 1);
   size_t phone = conformer_bytes(RP) + RP * (62 + 100 + 3 * ATT + 6 * 256 + 16) * 4 + (size_t)B * (64 + 2 * ATT + 24 * 256) * 4 + (1 << 16);
-  size_t frame = conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 80 * 3 + 2 * 256 + ATT + 160 + 2 * ATT + ATT + 8 * ATT) * 4 + (64 << 20);
+  size_t frame = conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 80 * 3 + 2 * 256 + ATT + 160 + 4 * ATT + ATT + 8 * ATT) * 4 + (64 << 20);
   size_t voc = 0;
   if (h->cfg.vocoder) {
     const size_t e = h->cfg.precision == TTS_COMPUTE_F32 ? 4 : 2;
@@ -713,7 +718,7 @@ int pipeline_control_regulate(Handle* h, float duration_scale, float pitch_scale
   }
   h->lf = Layout::make(h->frames.data(), B, 2);  // even begins: the Glow squeeze is a pure re-view
   const size_t RF = h->lf.total;
-  TTS_TRY(arena_reserve(h->frame, conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 3 * 80 + 2 * 256 + ATT + 160 + 2 * ATT + ATT + 8 * ATT + 64) * 4 + (64 << 20), st));
+  TTS_TRY(arena_reserve(h->frame, conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 3 * 80 + 2 * 256 + ATT + 160 + 4 * ATT + ATT + 8 * ATT + 64) * 4 + (64 << 20), st));
   Arena& a = h->frame;
   TTS_ALLOC(cat, a, float, RF * (80 + ATT));  // [refined mel | up-sampled text] = g_proj input
   TTS_TRY(hip_ok(hipMemsetAsync(cat, 0, RF * (80 + ATT) * 4, st), "clear frame buffer"));
@@ -797,6 +802,18 @@ int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
   TTS_ALLOC(x, a, float, (size_t)RS * 160);
   TTS_TRY(hip_ok(hipMemcpyAsync(x, z_noise, (size_t)RS * 160 * 4, hipMemcpyDeviceToDevice, st), "flow noise"));
   TTS_ALLOC(hs, a, float, (size_t)RS * 2 * ATT);  // [hidden state | skip sum]
+  // 16-bit configurations: one launch per WaveNet layer (tts_wavenet_layer); the state ping-pongs between hs and hs2
+  const bool fused = h->cfg.precision != TTS_COMPUTE_F32 && !h->no_fused_wavenet;
+  float* hs2 = nullptr;
+  TileTab t64;
+  if (fused) {
+    hs2 = arena_alloc<float>(a, (size_t)RS * 2 * ATT);
+    if (!hs2) {
+      set_error("tts_postflow: workspace exhausted");
+      return TTS_E_ARG;
+    }
+    TTS_TRY(tiles_of(h, ls, 64, st, &t64));
+  }
   TTS_ALLOC(acts, a, char, (size_t)RS * ATT * (b16 / 8));
   TTS_ALLOC(cond, a, float, (size_t)RS * 8 * ATT);
   float* skip = hs + ATT;
@@ -808,10 +825,24 @@ int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
     TTS_TRY(conv_of(h, p + "cond", &cnd));
     TTS_TRY(conv(h, start, T2(x, 160), T2(hs, 2 * ATT), ls, st));            // h = start(x0); the zero half clears the skip sum
     TTS_TRY(conv(h, cnd, T2(g, 2 * ATT), T2(cond, 8 * ATT), ls, st));       // squeeze of g = re-view [RS, 384]
+    float* cur = hs;
     for (int i = 0; i < 4; ++i) {
       ConvW inl, rs;
       TTS_TRY(conv_of(h, grp + "inl." + std::to_string(i), &inl));
       TTS_TRY(conv_of(h, grp + "res_skip." + std::to_string(i), &rs));
+      if (fused) {
+        float* nxt = cur == hs ? hs2 : hs;
+        TtsWavenetDesc w;
+        memset(&w, 0, sizeof(w));
+        w.hs_in = cur; w.ld_in = 2 * ATT; w.hs_out = nxt; w.ld_out = 2 * ATT;
+        w.cond = cond + (size_t)i * 2 * ATT; w.ld_cond = 8 * ATT;
+        w.w1 = inl.w16; w.b1 = inl.bias; w.w2 = rs.w16; w.b2 = rs.bias;
+        w.cout2 = rs.cout; w.compute = inl.compute16;
+        w.tiles = t64.dev; w.n_tiles = t64.n; w.tile_rows = 64;
+        TTS_TRY(tts_wavenet_layer(&w, st));
+        cur = nxt;
+        continue;
+      }
       ConvOpt oi;
       oi.preadd = cond + (size_t)i * 2 * ATT;
       oi.ld_preadd = 8 * ATT;
@@ -824,7 +855,7 @@ int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
     oe.aux = x + 80;
     oe.ld_aux = 160;
     oe.fp32_only = true;
-    TTS_TRY(conv(h, end, T2(skip, 2 * ATT), T2(x + 80, 160), ls, st, oe));
+    TTS_TRY(conv(h, end, T2(cur + ATT, 2 * ATT), T2(x + 80, 160), ls, st, oe));  // (four fused layers end in `hs` again)
     const float *winv, *ab, *al;
     TTS_TRY(fvec(h, p + "winv", &winv));
     TTS_TRY(fvec(h, p + "an_bias", &ab));
@@ -1059,6 +1090,7 @@ int tts_profile(TtsHandle* h, int32_t enable, const char* select) {
   }
   hh->prof.clear();
   hh->prof_on = enable != 0;
+  hh->prof_detail = enable == 2;  // 2: conv classes carry their shape ("conv1d_bf16<64x64>[192x384 k5 r10240]")
   hh->prof_select = select ? select : "";
   return TTS_OK;
 }

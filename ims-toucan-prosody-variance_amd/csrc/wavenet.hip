@@ -1,0 +1,215 @@
+// One WaveNet layer of the PostFlow's coupling blocks in one launch (16-bit MFMA configurations):
+//   acts = tanh(a) * sigmoid(g),  [a | g] = in_layer(h) (5 taps, 192 -> 384) + bias + cond          wavenet.py:104-110, :29-35
+//   [h | skip] += res_skip_layer(acts) (1 tap, 192 -> 384; last layer: 192 -> 192 into the skip sum)   wavenet.py:112-118
+// Two launches (tts_conv1d in GATED mode, then an accumulating 1-tap conv) cost 37 + 29 us per layer at batch 32 - 72 layers per
+// pass - almost all of it fixed per-launch / per-slab latency on tiny GEMMs (K = 192).  Here one 256-thread workgroup owns 64
+// frames of one utterance and ALL output channels: the gate activations never leave LDS and the hidden state is read and
+// written once.  Because a 5-tap conv reads two frames either side of the tile, the hidden state cannot be updated in place:
+// the layer reads hs_in and writes hs_out (the host ping-pongs two buffers).
+//
+// Both products run transposed (weights are the MFMA A operand, accumulator row = output channel, lane = frame), so epilogues
+// work on float4 / packed 8-byte pieces of a frame's row (see resblock.hip).  Weights stream as 32-channel slabs (24 KB) through
+// a THREE-deep LDS ring filled by direct global->LDS loads (global_load_lds_dwordx4): no staging registers, two slabs in flight
+// across the raw s_barrier of a step, counted s_waitcnt vmcnt (cdna_hip_programming.md, "Pipelining across barriers" - this
+// kernel runs at one workgroup per CU and one wavefront per SIMD, the regime where that matters).
+#include "common.h"
+
+namespace tts {
+
+namespace {
+constexpr int WN_H = 192;            // hidden channels
+constexpr int WN_BM = 64;            // frames per workgroup
+constexpr int WN_TAPS = 5;
+constexpr int WN_XP = WN_H + 8;      // LDS pitch of the window / of acts (16-bit elements)
+constexpr int WN_KS = 32;            // channels per weight slab
+constexpr int WN_SLAB_BYTES = (WN_KS / 8) * 384 * 16;  // 24 KB: [4][384][8] 16-bit
+constexpr int WN_SLABS1 = WN_TAPS * (WN_H / WN_KS);    // 30 slab steps of the gated conv
+constexpr int WN_SLABS2 = WN_H / WN_KS;                // 6 of the res/skip conv
+}  // namespace
+
+template <bool F16>
+__global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  unsigned short* xs = reinterpret_cast<unsigned short*>(lds_raw);                       // [68][XP] window of h, later [64][XP] acts
+  unsigned char* ring = lds_raw + ((WN_BM + WN_TAPS - 1) * WN_XP * 2 + 255) / 256 * 256;  // [3][24 KB]
+  const TtsTile tile = d.tiles[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, lrow = lane & 31, lk = lane >> 5;
+  const int n2 = d.cout2;                       // 384 or 192
+  const int units2 = (WN_KS / 8) * n2;          // 16-byte units of a res/skip slab
+  const int total = WN_SLABS1 + WN_SLABS2;
+  const char* w1 = reinterpret_cast<const char*>(d.w1);
+  const char* w2 = reinterpret_cast<const char*>(d.w2);
+
+  // direct global -> LDS copy of weight slab s into ring[s % 3]: wave w moves units i*256 + w*64 + lane (1 KB per instruction)
+  auto issue = [&](int s) __attribute__((always_inline)) {
+    const bool second = s >= WN_SLABS1;
+    const int units = second ? units2 : (WN_KS / 8) * 384;
+    const char* src = second ? w2 + (size_t)(s - WN_SLABS1) * units2 * 16 : w1 + (size_t)s * WN_SLAB_BYTES;  // slabs are contiguous: [tap][k/8][n][8]
+    unsigned char* dst = ring + (size_t)(s % 3) * WN_SLAB_BYTES;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int u0 = i * 256 + wave * 64;
+      if (u0 < units)
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(u0 + lane) * 16),
+                                         (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 16), 16, 0, 0);
+    }
+  };
+  auto loads_of = [&](int s) __attribute__((always_inline)) {  // global_load_lds instructions THIS wave issues for slab s
+    if (s >= total) return 0;
+    const int units = s >= WN_SLABS1 ? units2 : (WN_KS / 8) * 384;
+    int n = 0;
+    for (int i = 0; i < 6; ++i) n += (i * 256 + wave * 64 < units) ? 1 : 0;
+    return n;
+  };
+
+  // ---- window of the hidden state: rows row0 - 2 .. row0 + 65 (zero outside the utterance = the conv's zero padding) -> 16-bit
+  {
+    constexpr int Q4 = WN_H / 4, ROWS = WN_BM + WN_TAPS - 1;
+    for (int e = tid; e < ROWS * Q4; e += 256) {
+      const int r = e / Q4, c4 = (e % Q4) * 4;
+      const int gr = tile.row0 - 2 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gr >= tile.seq_begin && gr < tile.seq_end) v = *reinterpret_cast<const float4*>(d.hs_in + (size_t)gr * d.ld_in + c4);
+      *reinterpret_cast<uint2*>(xs + r * WN_XP + c4) = make_uint2(pack16<F16>(v.x, v.y), pack16<F16>(v.z, v.w));
+    }
+  }
+  issue(0);
+  issue(1);
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+  auto wait_for = [&](int s) __attribute__((always_inline)) {  // slab s has landed; the loads of slab s + 1 may stay in flight
+    const int keep = loads_of(s + 1);
+    if (keep >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS stores (window / acts) are done before the barrier publishes them
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- gated conv: acc[0..2] = a, acc[3..5] = g for channels wn*96 + j*32 ..; frames wm*32 ..
+  for (int s = 0; s < WN_SLABS1; ++s) {
+    wait_for(s);
+    if (s + 2 < total) issue(s + 2);
+    const int tap = s / (WN_H / WN_KS), k0 = (s % (WN_H / WN_KS)) * WN_KS;
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % 3) * WN_SLAB_BYTES);
+#pragma unroll
+    for (int kk = 0; kk < WN_KS / 16; ++kk) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(xs + (wm * 32 + lrow + tap) * WN_XP + k0 + kk * 16 + lk * 8);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int col = (j < 3 ? 0 : WN_H) + wn * 96 + (j % 3) * 32 + lrow;
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(kk * 2 + lk) * 384 + col) * 8);
+        acc[j] = mfma16<F16>(w, x, acc[j]);
+      }
+    }
+  }
+  // ---- acts = tanh(a + bias + cond) * sigmoid(g + bias + cond) -> LDS (over the window), 16-bit
+  __builtin_amdgcn_s_barrier();  // every wave is done reading the window
+  {
+    const int t = wm * 32 + lrow, row = tile.row0 + t;
+    const bool live = row < tile.seq_end;
+    const float* cr = d.cond + (size_t)(live ? row : tile.seq_end - 1) * d.ld_cond;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int c = wn * 96 + j * 32 + 8 * rq + 4 * lk;
+        const float4 ba = *reinterpret_cast<const float4*>(d.b1 + c), bg = *reinterpret_cast<const float4*>(d.b1 + WN_H + c);
+        const float4 ca = *reinterpret_cast<const float4*>(cr + c), cg = *reinterpret_cast<const float4*>(cr + WN_H + c);
+        const float av[4] = {acc[j][4 * rq] + ba.x + ca.x, acc[j][4 * rq + 1] + ba.y + ca.y, acc[j][4 * rq + 2] + ba.z + ca.z, acc[j][4 * rq + 3] + ba.w + ca.w};
+        const float gv[4] = {acc[j + 3][4 * rq] + bg.x + cg.x, acc[j + 3][4 * rq + 1] + bg.y + cg.y, acc[j + 3][4 * rq + 2] + bg.z + cg.z,
+                             acc[j + 3][4 * rq + 3] + bg.w + cg.w};
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tanhf(av[q]) * (1.0f / (1.0f + expf(-gv[q])));
+        *reinterpret_cast<uint2*>(xs + t * WN_XP + c) = make_uint2(pack16<F16>(v[0], v[1]), pack16<F16>(v[2], v[3]));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+  }
+  // ---- res / skip conv: output channels wn * (n2 / 2) + j * 32 .., j < n2 / 64
+  const int half2 = n2 >> 1, nj = n2 >> 6;
+  for (int s = WN_SLABS1; s < total; ++s) {
+    wait_for(s);  // (also publishes acts on the first step)
+    if (s + 2 < total) issue(s + 2);
+    const int k0 = (s - WN_SLABS1) * WN_KS;
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % 3) * WN_SLAB_BYTES);
+#pragma unroll
+    for (int kk = 0; kk < WN_KS / 16; ++kk) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(xs + (wm * 32 + lrow) * WN_XP + k0 + kk * 16 + lk * 8);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j < nj) {
+          const int col = wn * half2 + j * 32 + lrow;
+          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(kk * 2 + lk) * n2 + col) * 8);
+          acc[j] = mfma16<F16>(w, x, acc[j]);
+        }
+      }
+    }
+  }
+  // ---- [h | skip] out = in + res_skip + bias (last layer: the skip half only)
+  {
+    const int row = tile.row0 + wm * 32 + lrow;
+    if (row < tile.seq_end) {
+      const int col0 = n2 == 384 ? 0 : WN_H;
+      const float* ir = d.hs_in + (size_t)row * d.ld_in + col0;
+      float* orow = d.hs_out + (size_t)row * d.ld_out + col0;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j < nj) {
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int c = wn * half2 + j * 32 + 8 * rq + 4 * lk;
+            const float4 b = *reinterpret_cast<const float4*>(d.b2 + c), x = *reinterpret_cast<const float4*>(ir + c);
+            *reinterpret_cast<float4*>(orow + c) = make_float4((acc[j][4 * rq] + b.x) + x.x, (acc[j][4 * rq + 1] + b.y) + x.y,
+                                                               (acc[j][4 * rq + 2] + b.z) + x.z, (acc[j][4 * rq + 3] + b.w) + x.w);
+          }
+        }
+      }
+    }
+  }
+}
+
+int wavenet_layer(const TtsWavenetDesc& d, hipStream_t st) {
+  TTS_CHECK_ARG(d.hs_in && d.hs_out && d.cond && d.w1 && d.b1 && d.w2 && d.b2 && d.tiles, "wavenet_layer: null pointer");
+  TTS_CHECK_ARG(d.hs_in != d.hs_out, "wavenet_layer: the hidden state cannot be updated in place (the 5-tap conv reads neighbouring tiles)");
+  TTS_CHECK_ARG(d.cout2 == 384 || d.cout2 == 192, "wavenet_layer: res/skip width %d (384, or 192 for the last layer)", d.cout2);
+  TTS_CHECK_ARG(d.compute == TTS_COMPUTE_BF16 || d.compute == TTS_COMPUTE_F16, "wavenet_layer: 16-bit MFMA configurations only (compute %d)", d.compute);
+  TTS_CHECK_ARG(d.tile_rows == WN_BM, "wavenet_layer: tile table must use %d rows, got %d", WN_BM, d.tile_rows);
+  TTS_CHECK_ARG((d.ld_in & 3) == 0 && (d.ld_out & 3) == 0 && (d.ld_cond & 3) == 0 && ((uintptr_t)d.hs_in & 15) == 0 && ((uintptr_t)d.hs_out & 15) == 0 &&
+                    ((uintptr_t)d.cond & 15) == 0 && ((uintptr_t)d.w1 & 15) == 0 && ((uintptr_t)d.w2 & 15) == 0 && ((uintptr_t)d.b1 & 15) == 0 &&
+                    ((uintptr_t)d.b2 & 15) == 0,
+                "wavenet_layer: rows and weights must be 16-byte aligned");
+  if (d.n_tiles == 0) return TTS_OK;
+  const size_t lds = ((size_t)(WN_BM + WN_TAPS - 1) * WN_XP * 2 + 255) / 256 * 256 + 3 * (size_t)WN_SLAB_BYTES;
+  static unsigned long long raised[2] = {0, 0};
+  const bool f16 = d.compute == TTS_COMPUTE_F16;
+  const void* k = f16 ? reinterpret_cast<const void*>(wavenet_layer_kernel<true>) : reinterpret_cast<const void*>(wavenet_layer_kernel<false>);
+  if (raise_lds_limit(k, raised[f16 ? 1 : 0]) != hipSuccess) {
+    set_error("wavenet_layer: raising the dynamic LDS limit failed");
+    return TTS_E_LAUNCH;
+  }
+  if (f16) hipLaunchKernelGGL(wavenet_layer_kernel<true>, dim3(d.n_tiles), dim3(256), lds, st, d);
+  else hipLaunchKernelGGL(wavenet_layer_kernel<false>, dim3(d.n_tiles), dim3(256), lds, st, d);
+  return launch_status("wavenet_layer");
+}
+
+}  // namespace tts
+
+extern "C" int tts_wavenet_layer(const TtsWavenetDesc* d, tts_stream_t stream) {
+  if (!d) {
+    tts::set_error("tts_wavenet_layer: null descriptor");
+    return TTS_E_ARG;
+  }
+  return tts::wavenet_layer(*d, reinterpret_cast<hipStream_t>(stream));
+}

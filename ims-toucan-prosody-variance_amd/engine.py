@@ -166,6 +166,19 @@ class Ops:
             capi.check(self.lib.tts_resblock_step(C.byref(d), self.stream()), "tts_resblock_step")
         return y
 
+    def wavenet_layer(self, inl, res_skip, hs_in, hs_out, cond, rag):
+        """Fused WaveNet layer (tts_wavenet_layer): hs_out = hs_in + res_skip(tanh.sigmoid(in_layer(h) + cond)); 16-bit modes only."""
+        tiles, n = rag.tiles(64)
+        d = capi.TtsWavenetDesc()
+        d.hs_in, d.ld_in, d.hs_out, d.ld_out = hs_in.data_ptr(), _ld(hs_in), hs_out.data_ptr(), _ld(hs_out)
+        d.cond, d.ld_cond = cond.data_ptr(), _ld(cond)
+        d.w1, d.b1, d.w2, d.b2 = inl.w16.data_ptr(), inl.bias.data_ptr(), res_skip.w16.data_ptr(), res_skip.bias.data_ptr()
+        assert inl.compute16 == res_skip.compute16 != COMPUTE_F32 and inl.wn == 384 and inl.taps == 5 and res_skip.wn == res_skip.cout
+        d.cout2, d.compute = res_skip.cout, inl.compute16
+        d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n, 64
+        capi.check(self.lib.tts_wavenet_layer(C.byref(d), self.stream()), "tts_wavenet_layer")
+        return hs_out
+
     def layernorm(self, x, y, gamma, beta, rows, c, eps=1e-12):
         capi.check(self.lib.tts_layernorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), gamma.data_ptr(), beta.data_ptr(), rows, c, eps,
                                           self.stream()), "tts_layernorm")
@@ -683,6 +696,9 @@ class AcousticEngine:
         x = ops.empty(RS, 160)
         x.copy_(z_sq)
         hs = ops.empty(RS, 2 * ATT)  # [hidden state | skip sum] side by side: one accumulating conv per WaveNet layer updates both
+        # 16-bit configurations: one launch per WaveNet layer (tts_wavenet_layer), the state ping-pongs between two buffers
+        fused = self.bf16 and os.environ.get("TOUCAN_NO_FUSED_WAVENET") is None
+        hs2 = ops.empty(RS, 2 * ATT) if fused else None
         h, skip = hs[:, :ATT], hs[:, ATT:]
         acts = ops.empty(RS, ATT, dtype=self.dt16)  # read only by the res/skip conv (16-bit MFMA)
         cond = ops.empty(RS, 8 * ATT)
@@ -690,11 +706,17 @@ class AcousticEngine:
             blk = self.flow[b]
             ops.conv(blk["start"], x[:, :80], hs, rag_s)  # h = start(x0); the zero-weight second half clears the skip sum
             ops.conv(blk["cond"], g_sq, cond, rag_s)
+            cur = hs
             for i in range(4):
+                if fused:
+                    nxt = hs2 if cur is hs else hs
+                    ops.wavenet_layer(blk["inl"][i], blk["res_skip"][i], cur, nxt, cond[:, i * 2 * ATT:(i + 1) * 2 * ATT], rag_s)
+                    cur = nxt
+                    continue
                 ops.conv(blk["inl"][i], h, acts, rag_s, preadd=cond[:, i * 2 * ATT:(i + 1) * 2 * ATT])
                 ops.conv(blk["res_skip"][i], acts, hs if i < 3 else skip, rag_s, accumulate=True)  # h += res, skip += skip_out
             x1 = x[:, 80:]
-            ops.conv(blk["end"], skip, x1, rag_s, aux=x1)
+            ops.conv(blk["end"], cur[:, ATT:], x1, rag_s, aux=x1)  # (four fused layers end in `hs` again)
             ops.glow_invconv_actnorm(x, RS, 160, blk["winv"], blk["an_bias"], blk["an_logs"])
             if taps is not None and b in (17, 8, 0):
                 taps[f"glow_z_after_block{b}"] = x.clone()

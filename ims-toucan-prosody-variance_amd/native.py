@@ -160,15 +160,15 @@ class NativePipeline:
 
     def profile(self, enable, select=None):
         """Roofline leg: HIP events around the launches of one matrix-core kernel class (None: all) inside the stage entries."""
-        capi.check(self.lib.tts_profile(self.h, 1 if enable else 0, None if select is None else select.encode()), "tts_profile")
+        capi.check(self.lib.tts_profile(self.h, int(enable), None if select is None else select.encode()), "tts_profile")  # 2: per-shape conv classes
 
     def profile_summary(self):
         """class -> dict(launches, total_ms, avg_us, flops_per_launch, bytes_per_launch, elems_per_launch, tflops) (waits for the events)."""
         out = {}
-        name = C.create_string_buffer(64)
+        name = C.create_string_buffer(128)
         ms, fl, by, el = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         for i in range(int(self.lib.tts_profile_count(self.h))):
-            capi.check(self.lib.tts_profile_read(self.h, i, name, 64, C.byref(ms), C.byref(fl), C.byref(by), C.byref(el)), "tts_profile_read")
+            capi.check(self.lib.tts_profile_read(self.h, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by), C.byref(el)), "tts_profile_read")
             s = out.setdefault(name.value.decode(), dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, elems=0.0))
             s["launches"] += 1
             s["total_ms"] += ms.value

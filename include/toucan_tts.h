@@ -138,6 +138,26 @@ int tts_snake_fir_table(const float* filt /*[12], host*/, void* table /*host, TT
 int tts_resblock_tile_rows(int32_t c);
 int tts_resblock_step(const TtsResblockDesc* d, tts_stream_t stream);
 
+/*
+ * One WaveNet layer of a PostFlow coupling block in one launch (16-bit MFMA configurations):
+ *   acts = tanh(a) * sigmoid(g) with [a | g] = in_layer(h) + bias + cond   (5 taps, 192 -> 384; wavenet.py:104-110, :29-35)
+ *   hs_out = hs_in + res_skip_layer(acts) + bias                           (1 tap, 192 -> cout2; wavenet.py:112-118)
+ * hs = [hidden state h (192) | skip sum (192)] per packed row.  cout2 = 384: both halves are updated; cout2 = 192 (the last
+ * layer): only the skip half is written.  hs_out must be another buffer than hs_in (the 5-tap conv reads two frames either side
+ * of a tile).  Weights as packed for tts_conv1d(compute 1 / 2): w1 [5][24][384][8] (columns a | g), w2 [1][24][cout2][8].
+ */
+typedef struct {
+  const float* hs_in;  int32_t ld_in;
+  float* hs_out;       int32_t ld_out;
+  const float* cond;   int32_t ld_cond;  /* this layer's 384 conditioning columns (a | g) of every row */
+  const void* w1;      const float* b1;  /* bias [384]: a then g */
+  const void* w2;      const float* b2;  /* bias [cout2] */
+  int32_t cout2;       /* 384 or 192 */
+  int32_t compute;     /* TTS_COMPUTE_BF16 or TTS_COMPUTE_F16 */
+  const TtsTile* tiles; int32_t n_tiles; int32_t tile_rows; /* 64 */
+} TtsWavenetDesc;
+int tts_wavenet_layer(const TtsWavenetDesc* d, tts_stream_t stream);
+
 /* y[r,:] = LayerNorm(x[r,:]) * g + b over `c` channels, eps as given. Layers/LayerNorm.py:24-36 (eps 1e-12). */
 int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta,
                   int32_t rows, int32_t c, float eps, tts_stream_t stream);
@@ -335,7 +355,7 @@ int tts_synthesize_batch(TtsHandle* h, const float* text, const float* utt_emb, 
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 9
+#define TTS_ABI_VERSION 10
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -199,6 +199,31 @@ class Emulator:
             _store(d.y, sb, se, d.cout, d.ldy, v, fy)
         return 0
 
+    def tts_wavenet_layer(self, dref, stream):
+        """16-bit rounding points as in csrc/wavenet.hip: h -> 16 bit; acts -> 16 bit; fp32 accumulation and epilogues."""
+        self._count("wavenet_layer")
+        d = dref._obj
+        f16 = d.compute == capi.COMPUTE_F16
+        H, n2 = 192, d.cout2
+        w1 = _widen16(_arr(d.w1, 5 * H * 384, np.uint16), f16).reshape(5, H // 8, 384, 8).transpose(0, 1, 3, 2).reshape(5, H, 384).astype(np.float64)
+        w2 = _widen16(_arr(d.w2, H * n2, np.uint16), f16).reshape(H // 8, n2, 8).transpose(0, 2, 1).reshape(H, n2).astype(np.float64)
+        b1, b2 = _arr(d.b1, 384).astype(np.float32), _arr(d.b2, n2).astype(np.float32)
+        col0 = 0 if n2 == 384 else H
+        for sb, se, sid in _seqs_from_tiles(_tiles(d.tiles, d.n_tiles)):
+            n = se - sb
+            hs = _mat(d.hs_in, se, 384, d.ld_in)[sb:se].astype(np.float32)
+            h = _round16(hs[:, :H], f16).astype(np.float64)
+            hp = np.zeros((n + 4, H))
+            hp[2:2 + n] = h
+            acc = sum(hp[j:j + n] @ w1[j] for j in range(5)).astype(np.float32)
+            cond = _mat(d.cond, se, 384, d.ld_cond)[sb:se]
+            a = (acc[:, :H] + b1[:H]) + cond[:, :H]
+            g = (acc[:, H:] + b1[H:]) + cond[:, H:]
+            acts = _round16((np.tanh(a.astype(np.float64)) / (1.0 + np.exp(-g.astype(np.float64)))).astype(np.float32), f16).astype(np.float64)
+            out = ((acts @ w2).astype(np.float32) + b2) + hs[:, col0:col0 + n2]
+            _mat(d.hs_out, se, 384, d.ld_out)[sb:se, col0:col0 + n2] = out
+        return 0
+
     def tts_snake_fir_table(self, filt, table):
         return self._reallib().tts_snake_fir_table(filt, table)  # host-only arithmetic: the real library's (the emulator ignores the table)
 

@@ -448,3 +448,39 @@ def test_conv_post_snake(gpu, cpu, lengths, store):
 
     g, cc = both(gpu, cpu, run)
     close(g, cc, 2e-5)
+
+
+@pytest.mark.parametrize("compute", [capi.COMPUTE_BF16, capi.COMPUTE_F16])
+@pytest.mark.parametrize("cout2,lengths", [(384, [320, 63, 1, 130]), (192, [64, 65, 7])])
+def test_fused_wavenet_layer(gpu, cpu, compute, cout2, lengths):
+    """tts_wavenet_layer (gated 5-tap conv + cond, tanh.sigmoid, res/skip conv, state update) against the emulator on ragged
+    batches incl. tile-boundary lengths; and against the two-launch form it replaces (same rounding points, other summation order)."""
+    H = 192
+    w_in = rnd(2 * H, H, 5, seed=1, scale=1.0 / np.sqrt(5 * H)).numpy()
+    b_in = rnd(2 * H, seed=2, scale=0.1).numpy()
+    w_rs = rnd(cout2, H, 1, seed=3, scale=1.0 / np.sqrt(H)).numpy()
+    b_rs = rnd(cout2, seed=4, scale=0.1).numpy()
+
+    def run(ops, to, fused=True):
+        rag = Ragged(lengths, ops.device, align=2)
+        R = rag.total_rows
+        inl = packing.pack_conv(w_in, b_in, ops.device, mode=capi.MODE_GATED, bf16=PACK16[compute])
+        rs = packing.pack_conv(w_rs, b_rs, ops.device, bf16=PACK16[compute])
+        hs = to(rnd(R, 2 * H, seed=5))
+        cond = to(rnd(R, 8 * H, seed=6, scale=0.5))[:, 2 * H:4 * H]  # a 384-column slice of the [R, 1536] conditioning
+        out = to(rnd(R, 2 * H, seed=7))
+        if fused:
+            ops.wavenet_layer(inl, rs, hs, out, cond, rag)
+            return out if cout2 == 384 else out[:, H:]
+        acts = to(torch.zeros(R, H, dtype=DT16[compute]))
+        ops.conv(inl, hs[:, :H], acts, rag, preadd=cond, compute=compute)
+        ops.conv(rs, acts, hs if cout2 == 384 else hs[:, H:], rag, accumulate=True, compute=compute)
+        return hs if cout2 == 384 else hs[:, H:]
+
+    g, c = both(gpu, cpu, run)
+    rag = Ragged(lengths, "cpu", align=2)
+    rows = torch.cat([torch.arange(b, b + n) for b, n in zip(rag.begins, rag.lengths)])  # alignment rows are never written
+    close(g.cpu()[rows], c[rows], TOL[compute])
+    two = run(gpu, lambda t: t.to("cuda:0").contiguous(), fused=False)
+    torch.cuda.synchronize()
+    close(g.cpu()[rows], two.cpu()[rows], TOL[compute])
