@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
     const int units = second ? units2 : (WN_KS / 8) * 384;
     const char* src = second ? w2 + (size_t)(s - WN_SLABS1) * units2 * 16 : w1 + (size_t)s * WN_SLAB_BYTES;  // slabs are contiguous: [tap][k/8][n][8]
     unsigned char* dst = ring + (size_t)(s % 3) * WN_SLAB_BYTES;
+#ifdef WN_DIAG_NO_DMA  // (timing diagnostics only: no weight traffic, results are wrong)
+    if (s > 2) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int u0 = i * 256 + wave * 64;
@@ -62,20 +65,35 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
     return n;
   };
 
+  issue(0);  // the first two weight slabs land while the window is staged
+  issue(1);
   // ---- window of the hidden state: rows row0 - 2 .. row0 + 65 (zero outside the utterance = the conv's zero padding) -> 16-bit
   {
-    constexpr int Q4 = WN_H / 4, ROWS = WN_BM + WN_TAPS - 1;
-    for (int e = tid; e < ROWS * Q4; e += 256) {
-      const int r = e / Q4, c4 = (e % Q4) * 4;
-      const int gr = tile.row0 - 2 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gr >= tile.seq_begin && gr < tile.seq_end) v = *reinterpret_cast<const float4*>(d.hs_in + (size_t)gr * d.ld_in + c4);
-      *reinterpret_cast<uint2*>(xs + r * WN_XP + c4) = make_uint2(pack16<F16>(v.x, v.y), pack16<F16>(v.z, v.w));
+    // PER independent 16-byte loads per thread are in flight before the first is consumed (clamped addresses, no branches): one
+    // trip pays the HBM latency once, not once per load
+    constexpr int Q4 = WN_H / 4, ROWS = WN_BM + WN_TAPS - 1, TOTAL = ROWS * Q4, PER = 7;
+    for (int base = tid; base < TOTAL; base += 256 * PER) {
+      float4 v[PER];
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        int e = base + p * 256;
+        e = e < TOTAL ? e : TOTAL - 1;
+        const int r = e / Q4, c4 = (e % Q4) * 4;
+        const int gr = tile.row0 - 2 + r;
+        const int grc = gr < tile.seq_begin ? tile.seq_begin : (gr >= tile.seq_end ? tile.seq_end - 1 : gr);
+        v[p] = *reinterpret_cast<const float4*>(d.hs_in + (size_t)grc * d.ld_in + c4);
+        if (gr != grc) v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int p = 0; p < PER; ++p) {
+        const int e = base + p * 256;
+        if (e < TOTAL) {
+          const int r = e / Q4, c4 = (e % Q4) * 4;
+          *reinterpret_cast<uint2*>(xs + r * WN_XP + c4) = make_uint2(pack16<F16>(v[p].x, v[p].y), pack16<F16>(v[p].z, v[p].w));
+        }
+      }
     }
   }
-  issue(0);
-  issue(1);
-
   f32x16 acc[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j)
@@ -99,16 +117,28 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
     if (s + 2 < total) issue(s + 2);
     const int tap = s / (WN_H / WN_KS), k0 = (s % (WN_H / WN_KS)) * WN_KS;
     const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % 3) * WN_SLAB_BYTES);
+    // all fragments of the step first (14 LDS reads in flight), then the 12 MFMAs: with one wavefront per SIMD nothing else hides
+    // an LDS round trip in front of every MFMA, which is what the compiler's own interleaving produced
+    bf16x8 xf[WN_KS / 16], wf[WN_KS / 16][6];
 #pragma unroll
     for (int kk = 0; kk < WN_KS / 16; ++kk) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(xs + (wm * 32 + lrow + tap) * WN_XP + k0 + kk * 16 + lk * 8);
+      xf[kk] = *reinterpret_cast<const bf16x8*>(xs + (wm * 32 + lrow + tap) * WN_XP + k0 + kk * 16 + lk * 8);
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int col = (j < 3 ? 0 : WN_H) + wn * 96 + (j % 3) * 32 + lrow;
-        const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(kk * 2 + lk) * 384 + col) * 8);
-        acc[j] = mfma16<F16>(w, x, acc[j]);
+        wf[kk][j] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(kk * 2 + lk) * 384 + col) * 8);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef WN_DIAG_NO_MFMA
+#pragma unroll
+    for (int kk = 0; kk < WN_KS / 16; ++kk)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) acc[j] = mfma16<F16>(wf[kk][j], xf[kk], acc[j]);
+#else
+    for (int j = 0; j < 6; ++j) acc[j][0] += bf16_to_f32(wf[0][j][0]) + bf16_to_f32(xf[1][1]) + bf16_to_f32(wf[1][j][2]);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- acts = tanh(a + bias + cond) * sigmoid(g + bias + cond) -> LDS (over the window), 16-bit
   __builtin_amdgcn_s_barrier();  // every wave is done reading the window
@@ -128,7 +158,12 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
                              acc[j + 3][4 * rq + 3] + bg.w + cg.w};
         float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = tanhf(av[q]) * (1.0f / (1.0f + expf(-gv[q])));
+        for (int q = 0; q < 4; ++q) {
+          // hardware exp / reciprocal (a few ulp, far below the 16-bit rounding of acts): with one wavefront per SIMD the
+          // library tanhf / expf / IEEE division of 48 elements per lane were 6 us of a 37 us launch
+          const float th = 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * av[q])) - 1.0f;
+          v[q] = th * __builtin_amdgcn_rcpf(1.0f + __expf(-gv[q]));
+        }
         *reinterpret_cast<uint2*>(xs + t * WN_XP + c) = make_uint2(pack16<F16>(v[0], v[1]), pack16<F16>(v[2], v[3]));
       }
     }
@@ -144,18 +179,23 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
     if (s + 2 < total) issue(s + 2);
     const int k0 = (s - WN_SLABS1) * WN_KS;
     const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % 3) * WN_SLAB_BYTES);
+    bf16x8 xf[WN_KS / 16], wf[WN_KS / 16][6];
 #pragma unroll
     for (int kk = 0; kk < WN_KS / 16; ++kk) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(xs + (wm * 32 + lrow) * WN_XP + k0 + kk * 16 + lk * 8);
+      xf[kk] = *reinterpret_cast<const bf16x8*>(xs + (wm * 32 + lrow) * WN_XP + k0 + kk * 16 + lk * 8);
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
-        if (j < nj) {
-          const int col = wn * half2 + j * 32 + lrow;
-          const bf16x8 w = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(kk * 2 + lk) * n2 + col) * 8);
-          acc[j] = mfma16<F16>(w, x, acc[j]);
-        }
+        const int col = wn * half2 + (j < nj ? j : 0) * 32 + lrow;  // (j >= nj: a duplicate read, its MFMA is skipped)
+        wf[kk][j] = *reinterpret_cast<const bf16x8*>(wb + ((size_t)(kk * 2 + lk) * n2 + col) * 8);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < WN_KS / 16; ++kk)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        if (j < nj) acc[j] = mfma16<F16>(wf[kk][j], xf[kk], acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- [h | skip] out = in + res_skip + bias (last layer: the skip half only)
   {
