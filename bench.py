@@ -51,6 +51,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
     ap.add_argument("--graphs", action="store_true", help="replay the shape-static stages as HIP graphs (no per-kernel roofline leg)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="one HIP stream: every step runs acoustic model, then vocoder.  Default (native sequencer): two streams - the "
+                         "acoustic model of step k+1 runs beside the vocoder of step k (the small acoustic kernels fill the gaps the "
+                         "vocoder leaves); all K steps still complete inside the timed region")
     ap.add_argument("--sequencer", default="native", choices=["native", "python"],
                     help="native: the stage API (csrc/pipeline.hip sequences the kernels in C++; the product path); python: engine.py issues "
                          "every kernel-level call itself")
@@ -197,9 +201,39 @@ def main():
     if use_native:  # the stage API's input format (packed along the phoneme axis): resident in HBM before the timed region
         packed = pipe.pack_inputs(texts, embs, langs, durations=durs)
         z_sq = pipe.squeeze_noise(zs, [T] * B)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    overlap = use_native and not args.no_overlap
+    s_ac = s_voc = None
+    if overlap:
+        s_ac, s_voc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+    def step_overlapped(record=False):
+        """Two streams: the acoustic model of this step is enqueued on s_ac, its vocoder on s_voc behind an event; the next
+        step's acoustic model does not wait for this step's vocoder.  The mel handed over is forward()'s own copy."""
+        with torch.cuda.stream(s_ac):
+            if record:
+                ev[0].record(s_ac)
+            out = pipe.forward(None, None, packed=packed, z_sq=z_sq, vocode=False, **scales)
+            if record:
+                ev[1].record(s_ac)
+            done = torch.cuda.Event()
+            done.record(s_ac)
+        with torch.cuda.stream(s_voc):
+            s_voc.wait_event(done)
+            out["mel_packed"].record_stream(s_voc)
+            if record:
+                ev[3].record(s_voc)
+            wav, _ = pipe.vocode(out["mel_packed"], out["rag_mel"])
+            if record:
+                ev[2].record(s_voc)
+            if world > 1:
+                block = wav[: B * T * 384].contiguous()
+                dist.all_gather_into_tensor(gathered, block.cpu() if rehearsal else block)
+        return out, wav
 
     def step(record=False, tx=texts, em=embs, zz=zs, resident=True):
+        if overlap and resident:
+            return step_overlapped(record)
         if record:
             ev[0].record()
         if use_native and resident:
@@ -267,11 +301,17 @@ def main():
     t_ac = t_voc = 0.0
     for it in range(args.steps):
         log(f"timed step {it}")
-        out, wav = step(record=True)
-        ev[2].synchronize()
-        t_ac += ev[0].elapsed_time(ev[1]) * 1e-3
-        t_voc += ev[1].elapsed_time(ev[2]) * 1e-3
+        if overlap:  # no host wait between steps: the streams overlap consecutive steps; stage times from the last step only
+            out, wav = step(record=(it == args.steps - 1))
+        else:
+            out, wav = step(record=True)
+            ev[2].synchronize()
+            t_ac += ev[0].elapsed_time(ev[1]) * 1e-3
+            t_voc += ev[1].elapsed_time(ev[2]) * 1e-3
     torch.cuda.synchronize()
+    if overlap:  # (the two stages of one step, each running beside the other stage of a neighbouring step)
+        t_ac = ev[0].elapsed_time(ev[1]) * 1e-3 * args.steps
+        t_voc = ev[3].elapsed_time(ev[2]) * 1e-3 * args.steps
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -355,7 +395,8 @@ def main():
                        "acoustic_dtype": f"{args.dtype} MFMA / f32 activations" if args.dtype != "fp32" else "f32",
                        "vocoder_dtype": args.dtype if args.dtype != "fp32" else "f32", "parallelism": f"dp{world}",
                        "hip_graphs": bool(args.graphs),
-                       "sequencer": "native stage API (csrc/pipeline.hip)" if use_native else "python (engine.py)"},
+                       "sequencer": "native stage API (csrc/pipeline.hip)" if use_native else "python (engine.py)",
+                       "streams": "2 HIP streams: acoustic model of step k+1 beside the vocoder of step k" if overlap else "1 HIP stream"},
             "acoustic_mel_frames_per_s": world * frames_out * args.steps / t_ac,
             "vocoder_rtf": t_voc / (args.steps * audio_s),
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),

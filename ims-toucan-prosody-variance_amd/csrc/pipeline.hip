@@ -198,8 +198,10 @@ int tiles_of(Handle* h, const Layout& l, int tile_rows, hipStream_t st, TileTab*
     *out = it->second;
     return TTS_OK;
   }
-  if (h->tile_cache.size() > 512) {  // (no launch in flight may still read a table: drain first)
-    TTS_TRY(hip_ok(hipStreamSynchronize(st), "tile tables: sync before trimming the cache"));
+  if (h->tile_cache.size() > 512) {  // (no launch in flight may still read a table - on this stream or, when the caller runs the
+                                     // vocoder of one batch beside the acoustic model of the next, on another: drain the device first)
+    (void)st;
+    TTS_TRY(hip_ok(hipDeviceSynchronize(), "tile tables: sync before trimming the cache"));
     drop_tables(h);
   }
   std::vector<TtsTile> host;

@@ -35,6 +35,7 @@ class NativePipeline:
         self.multilingual, self.multispeaker = ac.multilingual, ac.multispeaker
         voc = None
         self.kind = vocoder_kind
+        self._streams = None  # (acoustic, vocoder) stream pair of forward_pipelined, made on first use
         if vocoder_sd is not None:
             assert vocoder_kind in ("hifigan", "bigvgan")
             voc = engine.VocoderEngine(vocoder_sd, vocoder_kind, "cpu", precision=self.precision, pack_only=True)
@@ -272,6 +273,50 @@ class NativePipeline:
         if vocode and self.kind is not None:
             out["wav"], out["wav_spans"] = self._vocode_internal(rag_out, st)
         return out
+
+    @torch.inference_mode()
+    def forward_pipelined(self, batches):
+        """Several batches, two HIP streams: the acoustic model of batch k+1 is enqueued beside the vocoder of batch k (the handle's
+        phoneme / frame arenas belong to the acoustic stages, its vocoder arenas to the vocoder; the mel crosses in forward()'s own
+        copy behind an event).  `batches` yields dicts of forward() keyword arguments; yields forward()'s result per batch with
+        ``wav`` / ``wav_spans``, ordered on the caller's current stream.  Same results as forward() batch by batch."""
+        assert self.kind is not None, "no vocoder was loaded into this handle"
+        with torch.cuda.device(self.device):
+            caller = torch.cuda.current_stream(self.device)
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            s_ac, s_voc = self._streams
+            s_ac.wait_stream(caller)
+            s_voc.wait_stream(caller)
+            pending = None
+
+            def finish(p):
+                out, done = p
+                caller.wait_event(done)
+                for key in ("wav", "mel_packed", "durations_packed", "pitch_packed", "energy_packed"):
+                    out[key].record_stream(caller)
+                return out
+
+            for kw in batches:
+                kw = dict(kw)
+                kw["vocode"] = False
+                with torch.cuda.stream(s_ac):
+                    out = self.forward(**kw)
+                    mel_ready = torch.cuda.Event()
+                    mel_ready.record(s_ac)
+                with torch.cuda.stream(s_voc):
+                    s_voc.wait_event(mel_ready)
+                    for key in ("mel_packed", "durations_packed", "pitch_packed", "energy_packed"):
+                        out[key].record_stream(s_voc)
+                    out["wav"], _ = self.vocode(out["mel_packed"], out["rag_mel"])
+                    out["wav_spans"] = [(384 * int(b0), 384 * int(n)) for b0, n in zip(out["rag_mel"].begins, out["rag_mel"].lengths)]
+                    done = torch.cuda.Event()
+                    done.record(s_voc)
+                if pending is not None:
+                    yield finish(pending)
+                pending = (out, done)
+            if pending is not None:
+                yield finish(pending)
 
     @torch.inference_mode()
     def predict_frame_counts(self, texts, utt_embs, lang_ids=None, pitch=None, energy=None, duration_scaling_factor=1.0,

@@ -159,3 +159,30 @@ def test_synthesize_batch_one_call_and_error_paths(pipes):
     assert lib.tts_encoder(h2, p(text), p(emb), p(lang), lens, B, st) != 0 and b"was not loaded" in lib.tts_last_error()
     assert lib.tts_destroy(h2) == 0
     assert pipe.workspace_bytes(32, 128, 640) > pipe.workspace_bytes(1, 128, 640) > 0
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_pipelined_batches_equal_one_batch_at_a_time(precision):
+    """forward_pipelined (acoustic model of batch k+1 on one HIP stream beside the vocoder of batch k on another): six batches
+    of different shapes, twice over, give bit for bit what forward() gives batch by batch."""
+    names = [("R128", "R20"), ("R97",), ("R64", "R128", "R97"), ("R20",), ("R128", "R97", "R64", "R20"), ("R64", "R20")]
+    pipe = native.NativePipeline(fw.acoustic_state_dict(), fw.bigvgan_state_dict(), "bigvgan", DEV, precision=precision)
+    batches = []
+    for group in names * 2:
+        gs = [_gold(n) for n in group]
+        texts, embs, langs, zs = _inputs(gs)
+        batches.append(dict(texts=[t.to(DEV) for t in texts], utt_embs=embs.to(DEV), lang_ids=langs, z_noise=[z.to(DEV) for z in zs],
+                            durations=[torch.from_numpy(g["gold_durations"]).to(DEV) for g in gs]))
+    want = []
+    for kw in batches:
+        out = pipe.forward(**kw)
+        want.append(([m.clone() for m in out["mel"]], out["wav"].clone(), list(out["wav_spans"])))
+    torch.cuda.synchronize()
+    got = list(pipe.forward_pipelined(batches))
+    assert len(got) == len(want)
+    for k, (out, (mel, wav, spans)) in enumerate(zip(got, want)):
+        assert out["wav_spans"] == spans
+        for m_got, m_want in zip(out["mel"], mel):  # (alignment rows between utterances are never written: compare utterance by utterance)
+            assert torch.equal(m_got, m_want), k
+        for b0, n in spans:
+            assert torch.equal(out["wav"][b0:b0 + n], wav[b0:b0 + n]), (k, b0, n, float((out["wav"][b0:b0 + n] - wav[b0:b0 + n]).abs().max()))
