@@ -37,6 +37,23 @@ namespace tts {
 #define RB_C64_TPS 1        // taps per weight slab at C = 64 (tuning knob)
 #endif
 constexpr int RB_LEAD = 16;
+
+// Timing diagnostics (tools/build_variant.sh NAME -DRB_DIAG_CLOCK[=wave]): every phase boundary of the matrix-core-snake path is
+// stamped with s_memtime; one wavefront per workgroup stores its stamps into g_rb_trace, read back by
+// tts_rb_diag_trace.  The shipped library carries no stamp.
+#ifdef RB_DIAG_CLOCK
+constexpr int RB_TRACE_MAX = 40000;
+// per workgroup (plain stores, no atomics): [0..9] s_memtime stamps, [10] 100 MHz start, [11] 100 MHz end, [12] XCC_ID << 32 | HW_ID
+__device__ unsigned long long g_rb_trace[RB_TRACE_MAX][16];
+#define RB_STAMP(k_)                                                                             \
+  do {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[k_])::"memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#else
+#define RB_STAMP(k_)
+#endif
 // C <= 128: conv1 on M1 = 256 rows (8 waves), 224 output rows, whole-C weight slabs.
 // C == 256: conv1 on M1 = 128 rows (4 waves, 8 accumulators each), 96 output rows, 64-channel slabs (LDS: t1 alone is 66 KB).
 template <int C>
@@ -175,6 +192,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #define load_slab(step_) wreg.load(slab_src(step_), tid, slab_units(step_))
 #define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * slab_alloc, tid)
 #endif
+#ifdef RB_DIAG_CLOCK
+  unsigned long long stamp[10];
+#endif
+#ifdef RB_DIAG_CLOCK
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  RB_STAMP(0);
   load_slab(0);
   store_slab(0);
 
@@ -251,6 +275,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         fir.row_begin = __builtin_amdgcn_readfirstlane(16 * t_lo); fir.n_tiles = __builtin_amdgcn_readfirstlane(t_hi - t_lo);
         fir.er = expf(d.alpha1[chn]) * 0.15915494309189535f;
         fir.inv_b = 1.0f / (expf(d.beta1[chn]) + 1e-9f);
+        RB_STAMP(1);
         __syncthreads();
         FirTaps ft;
 #pragma unroll
@@ -258,7 +283,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #ifndef RB_DIAG_NO_SWEEP1  // (timing diagnostics only: tools/build_variant.sh NAME -DRB_DIAG_NO_SWEEP1)
         fir.begin(d.fir_tab, lane);
         __syncthreads();
+        RB_STAMP(2);
         fir.template sweep<F16>(ft, lane);
+        RB_STAMP(3);
 #endif
       }
     } else if (snake) {
@@ -369,6 +396,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 
   // ------------------------------------------------------------------ t1 = conv1 + bias (LeakyReLU applied here), bf16 in LDS
   // t1 row i <-> local frame l0 - LEAD + i
+  RB_STAMP(4);
   __syncthreads();  // every wave is done reading xa (t1 overlays it)
   {
     // Both convs run transposed (weights as the A operand): a lane owns ONE frame and its accumulator registers hold four
@@ -399,6 +427,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   }
   __syncthreads();
+  RB_STAMP(5);
   if (MFIR && snake) {
     if constexpr (MFIR) {
       // act2 in place on t1 (rows [0, M1) of the window; the 6 rows on either side only feed outputs conv2 never reads)
@@ -418,7 +447,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #ifndef RB_DIAG_NO_SWEEP2
       fir.begin(d.fir_tab, lane);
       __syncthreads();
+      RB_STAMP(6);
       fir.template sweep<F16>(ft, lane);
+      RB_STAMP(7);
 #endif
     }
   } else if (snake) {
@@ -500,6 +531,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   }
 
+  RB_STAMP(8);
   // ------------------------------------------------------------------ epilogue
   // transposed accumulators again: lane = output row, registers = groups of four consecutive channels.  Residual read, scaling,
   // optional accumulate and the store happen in registers on 8-byte (16-bit tensors) or 16-byte (fp32) pieces of the row: no
@@ -552,7 +584,28 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       }
     }
   }
+#ifdef RB_DIAG_CLOCK
+  RB_STAMP(9);
+  if (MFIR && snake && tid == 64 * (RB_DIAG_CLOCK + 0)) {
+    if (blockIdx.x < RB_TRACE_MAX) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) g_rb_trace[blockIdx.x][k] = stamp[k];
+      g_rb_trace[blockIdx.x][10] = rt0;
+      g_rb_trace[blockIdx.x][11] = __builtin_amdgcn_s_memrealtime();
+      g_rb_trace[blockIdx.x][12] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+  }
+#endif
 }
+
+#ifdef RB_DIAG_CLOCK
+}  // namespace tts
+extern "C" int tts_rb_diag_trace(unsigned long long* out, int n_workgroups) {
+  if (n_workgroups > tts::RB_TRACE_MAX) n_workgroups = tts::RB_TRACE_MAX;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tts::g_rb_trace), (size_t)n_workgroups * 128) == hipSuccess ? n_workgroups : -1;
+}
+namespace tts {
+#endif
 
 #undef load_slab
 #undef store_slab
