@@ -169,6 +169,19 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   const int steps1 = NCH * spc, total_steps = 2 * steps1;
   const int slab_alloc = (d.taps < TPS ? d.taps : TPS) * TAPW;  // LDS elements per slab buffer
 
+  // constants every phase would otherwise fetch from global memory with the latency exposed (both biases, and the FIR operand
+  // table of the matrix-core snake, which both sweeps load): copied into LDS once, visible after the staging barrier
+  float* cst_b1 = reinterpret_cast<float*>(ws + (size_t)2 * slab_alloc);    // [C]
+  float* cst_b2 = cst_b1 + C;                                               // [C]
+  uint4* cst_fir = reinterpret_cast<uint4*>(cst_b2 + C);                    // [256] (MFIR && snake)
+  if (tid < C / 4) reinterpret_cast<float4*>(cst_b1)[tid] = reinterpret_cast<const float4*>(d.b1)[tid];
+  else if (tid < C / 2) reinterpret_cast<float4*>(cst_b2)[tid - C / 4] = reinterpret_cast<const float4*>(d.b2)[tid - C / 4];
+  // (C = 128 has no 4 KB of LDS left at 11 taps x dilation 5, but registers to spare: there the table's 16 registers stay live)
+  constexpr bool FIR_LDS = MFIR && C < 128;
+  if (FIR_LDS && snake && tid >= RB_THREADS - 256) cst_fir[tid - (RB_THREADS - 256)] = reinterpret_cast<const uint4*>(d.fir_tab)[tid - (RB_THREADS - 256)];
+  SnakeFir fir_const;
+  if (MFIR && !FIR_LDS && snake) fir_const.load_constants(d.fir_tab, lane);
+
   RbSlab<UNITS, UPT, RB_THREADS> wreg;
   // weight slab of step `step`: conv1 steps first, then conv2 (global layout [tap][C/8][C][8], one slab = one tap here)
   // (with TPS > 1 there is one channel chunk, so the taps of a slab are contiguous in global memory)
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   float f[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) f[k] = snake ? d.filt[k] : 0.0f;
+  float al2 = 0.0f, be2 = 0.0f;  // second snake's parameters of this lane's channel (matrix-core snake: fetched with the first one's)
 
   // ------------------------------------------------------------------ conv1 over act1(x)
   int step = 0;
@@ -222,8 +236,15 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     if (MFIR && snake) {
       if constexpr (MFIR) {
         // raw x (as fp16, zero outside the utterance) into the whole image, then both FIR filters of act1 on the matrix cores, in place
-        constexpr int Q8 = C / 8, PER = 4;
+        // (16-bit x: every load of the image is in flight before the first one is consumed - one memory round trip, not two or three)
+        constexpr int Q8 = C / 8, PER = IOB ? (C == 128 ? 11 : (C == 64 ? 6 : 3)) : 4;
         const int total = img_rows * Q8;
+        constexpr int CB = C / 16, SEG = 8 / CB;
+        const int cb = wave % CB, seg = wave / CB;
+        const int chn = cb * 16 + (lane & 15);
+        const float al1 = d.alpha1[chn], be1 = d.beta1[chn];  // (issued ahead of the image loads; consumed after them)
+        al2 = d.alpha2[chn];
+        be2 = d.beta2[chn];
         for (int base = tid; base < total; base += RB_THREADS * PER) {
           uint4 v[PER], v2[PER];
 #pragma unroll
@@ -264,24 +285,23 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
             *reinterpret_cast<uint4*>(img + r * XP + c8) = o;
           }
         }
-        constexpr int CB = C / 16, SEG = 8 / CB;
-        const int cb = wave % CB, seg = wave / CB;
         const int tiles_total = (win_rows + 15) / 16;
         const int t_lo = seg * tiles_total / SEG, t_hi = (seg + 1) * tiles_total / SEG;
-        const int chn = cb * 16 + (lane & 15);
         SnakeFir fir;
         fir.img = img; fir.pitch = XP;
         fir.frame0 = wbase - PADR; fir.T = T; fir.ch0 = cb * 16;
         fir.row_begin = __builtin_amdgcn_readfirstlane(16 * t_lo); fir.n_tiles = __builtin_amdgcn_readfirstlane(t_hi - t_lo);
-        fir.er = expf(d.alpha1[chn]) * 0.15915494309189535f;
-        fir.inv_b = 1.0f / (expf(d.beta1[chn]) + 1e-9f);
+        fir.er = expf(al1) * 0.15915494309189535f;
+        fir.inv_b = 1.0f / (expf(be1) + 1e-9f);
         RB_STAMP(1);
         __syncthreads();
         FirTaps ft;
 #pragma unroll
         for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
 #ifndef RB_DIAG_NO_SWEEP1  // (timing diagnostics only: tools/build_variant.sh NAME -DRB_DIAG_NO_SWEEP1)
-        fir.begin(d.fir_tab, lane);
+        if constexpr (FIR_LDS) fir.load_constants(cst_fir, lane);
+        else fir.copy_constants(fir_const);
+        fir.begin(lane);
         __syncthreads();
         RB_STAMP(2);
         fir.template sweep<F16>(ft, lane);
@@ -411,7 +431,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         const int n0 = j * 32 + 8 * rq + 4 * lk;
-        const float4 bb = *reinterpret_cast<const float4*>(d.b1 + n0);
+        const float4 bb = *reinterpret_cast<const float4*>(cst_b1 + n0);
         float v[4] = {acc[j][4 * rq] + bb.x, acc[j][4 * rq + 1] + bb.y, acc[j][4 * rq + 2] + bb.z, acc[j][4 * rq + 3] + bb.w};
         if (!snake) {
 #pragma unroll
@@ -434,18 +454,19 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       constexpr int CB = C / 16, SEG = 8 / CB;
       const int cb = wave % CB, seg = wave / CB;
       constexpr int tiles_total = RB_M1 / 16;
-      const int chn = cb * 16 + (lane & 15);
       SnakeFir fir;
       fir.img = img; fir.pitch = TP;  // (rows past M1 + 12 still hold act1(x): finite)
       fir.frame0 = l0 - RB_LEAD - PADR; fir.T = T; fir.ch0 = cb * 16;
       fir.row_begin = __builtin_amdgcn_readfirstlane(16 * (seg * tiles_total / SEG)); fir.n_tiles = tiles_total / SEG;
-      fir.er = expf(d.alpha2[chn]) * 0.15915494309189535f;
-      fir.inv_b = 1.0f / (expf(d.beta2[chn]) + 1e-9f);
+      fir.er = expf(al2) * 0.15915494309189535f;
+      fir.inv_b = 1.0f / (expf(be2) + 1e-9f);
       FirTaps ft;
 #pragma unroll
       for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
 #ifndef RB_DIAG_NO_SWEEP2
-      fir.begin(d.fir_tab, lane);
+      if constexpr (FIR_LDS) fir.load_constants(cst_fir, lane);
+      else fir.copy_constants(fir_const);
+      fir.begin(lane);
       __syncthreads();
       RB_STAMP(6);
       fir.template sweep<F16>(ft, lane);
@@ -506,6 +527,20 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   }
 
   // ------------------------------------------------------------------ conv2 (dilation 1) over t1; output row o <-> t1 row LEAD + o
+  // 16-bit x: the residual of this lane's output row is fetched now and waits in registers while conv2 runs (its latency is
+  // paid beside the MFMAs, not in the epilogue)
+  constexpr bool PREFETCH_RES = IOB && C <= 128;
+  uint2 xres[PREFETCH_RES ? TN : 1][4];
+  if constexpr (PREFETCH_RES) {
+    if (wave < RB_BM / 32) {
+      int row = tile.row0 + wave * 32 + lrow;
+      row = row < tile.seq_end ? row : tile.seq_end - 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) xres[j][rq] = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + j * 32 + 8 * rq + 4 * lk);
+    }
+  }
   for (int ch = 0; ch < NCH; ++ch) {
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       __syncthreads();
@@ -546,11 +581,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const int n0 = j * 32 + 8 * rq + 4 * lk;
-          const float4 bb = *reinterpret_cast<const float4*>(d.b2 + n0);
+          const float4 bb = *reinterpret_cast<const float4*>(cst_b2 + n0);
           float v[4] = {d.alpha * (acc[j][4 * rq] + bb.x), d.alpha * (acc[j][4 * rq + 1] + bb.y), d.alpha * (acc[j][4 * rq + 2] + bb.z),
                         d.alpha * (acc[j][4 * rq + 3] + bb.w)};
           if constexpr (IOB) {
-            const uint2 xr = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + n0);
+            uint2 xr;
+            if constexpr (PREFETCH_RES) xr = xres[j][rq];
+            else xr = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + n0);
             v[0] += d.res_scale * from16<F16>(xr.x & 0xFFFF);
             v[1] += d.res_scale * from16<F16>(xr.x >> 16);
             v[2] += d.res_scale * from16<F16>(xr.y & 0xFFFF);
@@ -617,7 +654,7 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
   const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
   const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
-  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2;
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 : 0);
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised

@@ -143,13 +143,18 @@ struct SnakeFir {
   }
 
   // everything a run needs from rows other wavefronts will overwrite: call before the workgroup barrier that precedes sweep()
-  __device__ __forceinline__ void begin(const void* __restrict__ fir_tab, int lane) {
-    // interior constants: built once per filter on the host (snake_fir_table below), one 16-byte load per operand and lane
+  // interior constants: built once per filter on the host (snake_fir_table), one 16-byte load per operand and lane
+  __device__ __forceinline__ void load_constants(const void* fir_tab, int lane) {
     const bf16x8* tab = reinterpret_cast<const bf16x8*>(fir_tab);
     ua0 = tab[0 * 64 + lane];
     ua1 = tab[1 * 64 + lane];
     da0 = tab[2 * 64 + lane];
     da1 = tab[3 * 64 + lane];
+  }
+  __device__ __forceinline__ void copy_constants(const SnakeFir& o) {
+    ua0 = o.ua0; ua1 = o.ua1; da0 = o.da0; da1 = o.da1;
+  }
+  __device__ __forceinline__ void begin(int lane) {
     x_head = load_x(row_begin, lane);
     x_tail = load_x(row_begin + 16 * n_tiles, lane);
   }
