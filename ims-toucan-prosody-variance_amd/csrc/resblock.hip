@@ -17,6 +17,7 @@
 //   * epilogue: + bias2, alpha, + res_scale * x (re-read from global, L2-resident), optional accumulate, fp32 store.
 // Rows outside the utterance are zero after each activation (the reference zero-pads every conv per utterance).
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -38,12 +39,19 @@ namespace tts {
 #endif
 constexpr int RB_LEAD = 16;
 
+// Work queues of the persistent tile loop: one 16-word slot per launch in flight (zero when a launch starts; its last workgroup
+// leaves it zero again).  Launches take slots round-robin; two launches could only share a slot if RB_QUEUE_SLOTS launches
+// of this kernel were in flight on the device at once.
+constexpr int RB_QUEUE_SLOTS = 256;
+__device__ unsigned int g_rb_queue[RB_QUEUE_SLOTS][16];
+
 // Timing diagnostics (tools/build_variant.sh NAME -DRB_DIAG_CLOCK[=wave]): every phase boundary of the matrix-core-snake path is
 // stamped with s_memtime; one wavefront per workgroup stores its stamps into g_rb_trace, read back by
 // tts_rb_diag_trace.  The shipped library carries no stamp.
 #ifdef RB_DIAG_CLOCK
 constexpr int RB_TRACE_MAX = 40000;
-// per workgroup (plain stores, no atomics): [0..9] s_memtime stamps, [10] 100 MHz start, [11] 100 MHz end, [12] XCC_ID << 32 | HW_ID
+// per workgroup (plain stores, no atomics): [0..8] shader cycles per phase summed over its tiles, [9] tiles, [10] 100 MHz start,
+// [11] 100 MHz end, [12] XCC_ID << 32 | HW_ID
 __device__ unsigned long long g_rb_trace[RB_TRACE_MAX][16];
 #define RB_STAMP(k_)                                                                             \
   do {                                                                                           \
@@ -127,7 +135,7 @@ struct RbSlab {
 //       VALU form; the activation window then carries 6 raw rows in front and behind (the filters' reach) and is transformed in place
 template <int C, bool IOB, bool F16, bool MFIR>
 // (C = 32: with the prefetching snake two spill-free workgroups per CU beat three at the 80-register cap by ~10 %)
-__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d) {
+__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d, const int queue_slot) {
   constexpr int RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   constexpr int KC = RbCfg<C>::KC;        // channels per weight slab (all of them for C <= 128: one step per tap, act1(x) staged once)
   constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
@@ -141,12 +149,41 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   constexpr int UPT = (UNITS + RB_THREADS - 1) / RB_THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
-  // Workgroups are dealt to the 8 XCDs round-robin (b % 8); neighbouring tiles share their halo rows, so give every XCD a
-  // contiguous run of tiles: its private L2 then serves the halo the neighbour already fetched.
-  // (XCD x owns q + (x < r) consecutive tiles, q = n / 8, r = n % 8: a bijection for every n)
-  const int q8 = d.n_tiles >> 3, r8 = d.n_tiles & 7, xcd = blockIdx.x & 7;
-  const int tile_idx = xcd * q8 + (xcd < r8 ? xcd : r8) + (blockIdx.x >> 3);
-  const TtsTile tile = d.tiles[tile_idx];
+  // Persistent workgroups over a work queue: the grid is one residency's worth of workgroups, each takes tile after tile until
+  // none is left (workgroups run at visibly different speeds - 765 .. 1013 us for the same 34 tiles was measured with a static
+  // split - so the split is dynamic).  Neighbouring tiles share their halo rows, so every XCD owns a contiguous run of tiles
+  // (q + (x < r) of them, q = n / 8, r = n % 8: a bijection for every n) and a workgroup draws from the run of the XCD it really
+  // runs on (XCC_ID register): the tiles in flight on an XCD at any moment are neighbours, and its private L2 serves the halo
+  // the neighbour already fetched.  (No stealing between runs: the XCDs get equal shares and run at equal speed.)
+  // queue[x] = next ticket of XCD x's run, queue[8] = workgroups that are done; the last one to finish zeroes the slot again.
+  unsigned int* queue = g_rb_queue[queue_slot];
+  const int q8 = d.n_tiles >> 3, r8 = d.n_tiles & 7;
+  const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;  // HW_REG_XCC_ID[3:0]
+  auto run_lo_of = [&](int x) __attribute__((always_inline)) { return x * q8 + (x < r8 ? x : r8); };
+  auto run_n_of = [&](int x) __attribute__((always_inline)) { return q8 + (x < r8 ? 1 : 0); };
+  // the tile a ticket of the own run stands for, -1 past the end of the run
+  const int run_lo = run_lo_of(xcc), run_n = run_n_of(xcc);
+  auto tile_of_ticket = [&](unsigned int ticket) __attribute__((always_inline)) { return ticket < (unsigned int)run_n ? run_lo + (int)ticket : -1; };
+  // (behind the queue's atomics the compiler no longer proves the tile table read-only and fetches entries with vector loads:
+  // the values are wave-uniform, so they go back to scalar registers - every address below is built from them)
+  auto load_tile = [&](int idx) __attribute__((always_inline)) {
+    const TtsTile v = d.tiles[idx];
+    TtsTile r;
+    r.row0 = __builtin_amdgcn_readfirstlane(v.row0);
+    r.seq_begin = __builtin_amdgcn_readfirstlane(v.seq_begin);
+    r.seq_end = __builtin_amdgcn_readfirstlane(v.seq_end);
+    r.seq_id = __builtin_amdgcn_readfirstlane(v.seq_id);
+    return r;
+  };
+  auto retire = [&](int tid_) __attribute__((always_inline)) {
+    if (tid_ == 0) {
+      const unsigned int done = atomicAdd(&queue[8], 1u);
+      if (done == gridDim.x - 1) {  // every other workgroup has drawn its last ticket before it counted itself here
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicExch(&queue[i], 0u);
+      }
+    }
+  };
 
   const int h1 = (d.taps - 1) / 2 * d.dil, h2 = (d.taps - 1) / 2;
   const int win_rows = RB_M1 + 2 * h1;
@@ -160,9 +197,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   unsigned short* t1 = xa;                                                  // [M1][TP]
   unsigned short* ws = img + (xa_elems > t1_elems ? xa_elems : t1_elems);   // [2][SLAB]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lk = lane >> 5;
-  const int T = tile.seq_end - tile.seq_begin;
-  const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (prologue only: the tile loop re-derives them, see there)
   const bool snake = d.act == TTS_PRE_SNAKE;
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
   const int spc = (d.taps + TPS - 1) / TPS;  // slab steps per channel chunk
@@ -173,7 +208,16 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   // table of the matrix-core snake, which both sweeps load): copied into LDS once, visible after the staging barrier
   float* cst_b1 = reinterpret_cast<float*>(ws + (size_t)2 * slab_alloc);    // [C]
   float* cst_b2 = cst_b1 + C;                                               // [C]
-  uint4* cst_fir = reinterpret_cast<uint4*>(cst_b2 + C);                    // [256] (MFIR && snake)
+  float* cst_snk = cst_b2 + C;                                              // [4][C]: e^a1 / 2 pi, 1 / (e^b1 + 1e-9), same for the second snake (FIR_LDS)
+  uint4* cst_fir = reinterpret_cast<uint4*>(cst_snk + (MFIR && C < 128 ? 4 * C : 0));  // [256] (FIR_LDS && snake)
+  unsigned char* cst_dump = reinterpret_cast<unsigned char*>(cst_fir + (MFIR && C < 128 ? 256 : 0));  // [256 B] (L2PF: see l2_prefetch)
+  int* cst_ticket = reinterpret_cast<int*>(cst_dump + (MFIR ? 256 : 0));                             // [4] the next tile of this workgroup
+  unsigned int ticket_raw = 0;
+  float f[12];  // (scalar loads: ahead of the first atomic)
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+    f[k] = snake ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d.filt[k]))) : 0.0f;  // (kept in scalar registers)
+  if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);  // (in flight while the constants below are fetched)
   if (tid < C / 4) reinterpret_cast<float4*>(cst_b1)[tid] = reinterpret_cast<const float4*>(d.b1)[tid];
   else if (tid < C / 2) reinterpret_cast<float4*>(cst_b2)[tid - C / 4] = reinterpret_cast<const float4*>(d.b2)[tid - C / 4];
   // (C = 128 has no 4 KB of LDS left at 11 taps x dilation 5, but registers to spare: there the table's 16 registers stay live)
@@ -206,25 +250,136 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * slab_alloc, tid)
 #endif
 #ifdef RB_DIAG_CLOCK
-  unsigned long long stamp[10];
-#endif
-#ifdef RB_DIAG_CLOCK
+  unsigned long long stamp[10], phase_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  int n_iter = 0;
 #endif
-  RB_STAMP(0);
+
+  // ---- matrix-core snake: staging of the raw x image (16-byte units; row r of the image <-> local frame l0 - LEAD - h1 - 6 + r).
+  // 16-bit x: every unit of the image fits one round of PERX loads per thread, and that round is issued ONE TILE AHEAD (before
+  // conv2 of the previous tile; before the weight and constant loads for the first tile) - its memory latency never shows.
+  constexpr int Q8 = C / 8;
+  constexpr int PERX = !MFIR ? 1 : (IOB ? (C == 128 ? 11 : (C == 64 ? 6 : 3)) : 4);
+  // one-tile-ahead prefetch into registers: C = 128 only (one workgroup per CU, 256 registers per lane).  C <= 64 runs two
+  // workgroups per CU on 128 registers: there the next image is only pulled towards the L2 (l2_prefetch below) and loaded at the
+  // top of its tile.  fp32 x would need twice the registers: loaded in place.
+  constexpr bool XPF = MFIR && IOB && C == 128;
+  constexpr bool L2PF = MFIR && !XPF;
+  const int img_units = img_rows * Q8;
+  uint4 xv[PERX], xv2[(MFIR && !IOB) ? PERX : 1];
+  auto stage_issue = [&](const TtsTile& tl, int base) __attribute__((always_inline)) {
+    const int Tn = tl.seq_end - tl.seq_begin, fr0 = tl.row0 - tl.seq_begin - RB_LEAD - h1 - PADR;
+#pragma unroll
+    for (int p = 0; p < PERX; ++p) {
+      int e = base + p * RB_THREADS;
+      e = e < img_units ? e : img_units - 1;
+      const int r = e / Q8, c8 = (e % Q8) * 8;
+      const int t = fr0 + r;
+      const int tc = t < 0 ? 0 : (t > Tn - 1 ? Tn - 1 : t);  // (rows outside the utterance are zeroed when they are stored)
+      if constexpr (IOB) {
+        xv[p] = *reinterpret_cast<const uint4*>(xh + (size_t)(tl.seq_begin + tc) * d.ldx + c8);
+      } else {
+        xv[p] = *reinterpret_cast<const uint4*>(d.x + (size_t)(tl.seq_begin + tc) * d.ldx + c8);
+        xv2[p] = *reinterpret_cast<const uint4*>(d.x + (size_t)(tl.seq_begin + tc) * d.ldx + c8 + 4);
+      }
+    }
+  };
+  auto stage_commit = [&](const TtsTile& tl, int base) __attribute__((always_inline)) {
+    const int Tn = tl.seq_end - tl.seq_begin, fr0 = tl.row0 - tl.seq_begin - RB_LEAD - h1 - PADR;
+#pragma unroll
+    for (int p = 0; p < PERX; ++p) {
+      const int e = base + p * RB_THREADS;
+      if (e >= img_units) continue;
+      const int r = e / Q8, c8 = (e % Q8) * 8;
+      const int t = fr0 + r;
+      uint4 o;
+      if constexpr (IOB && F16) {
+        o = xv[p];
+      } else if constexpr (IOB) {  // bf16 -> fp16 (exact for |x| in fp16's range)
+        const unsigned int w4[4] = {xv[p].x, xv[p].y, xv[p].z, xv[p].w};
+        unsigned int o4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o4[q] = pack16<true>(bf16_to_f32(w4[q] & 0xFFFF), bf16_to_f32(w4[q] >> 16));
+        o = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+      } else {
+        auto fb = [](unsigned int b) { return __builtin_bit_cast(float, b); };
+        o = make_uint4(pack16<true>(fb(xv[p].x), fb(xv[p].y)), pack16<true>(fb(xv[p].z), fb(xv[p].w)),
+                       pack16<true>(fb(xv2[p].x), fb(xv2[p].y)), pack16<true>(fb(xv2[p].z), fb(xv2[p].w)));
+      }
+      // frames outside the utterance and the surplus rows behind the window: zeros
+      if (t < 0 || t >= Tn || r >= win_rows + 2 * PADR) o = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(img + r * XP + c8) = o;
+    }
+  };
+  if (tid == 0) cst_ticket[0] = tile_of_ticket(ticket_raw);
+  __syncthreads();
+  int cur_tile = __builtin_amdgcn_readfirstlane(cst_ticket[0]);
+  if (cur_tile < 0) {  // (more workgroups than tiles)
+    retire(tid);
+    return;
+  }
+  TtsTile tile = load_tile(cur_tile);
+  if (XPF && snake) stage_issue(tile, tid);
+  // one 4-byte load per 128-byte line of the next tile's image, result never used: the line is in this XCD's L2 when the tile
+  // starts.  The loads go global -> LDS (a 256-byte dump area all wavefronts share): no destination register that would have to
+  // stay reserved while they are in flight, and the compiler counts them like any other load.
+  auto l2_prefetch = [&](const TtsTile& tl, int tid_) __attribute__((always_inline)) {
+    constexpr int ROW_BYTES = C * (IOB ? 2 : 4), LPR = (ROW_BYTES + 127) / 128;
+    const int Tn = tl.seq_end - tl.seq_begin, fr0 = tl.row0 - tl.seq_begin - RB_LEAD - h1 - PADR;
+    for (int e = tid_; e < (win_rows + 2 * PADR) * LPR; e += RB_THREADS) {
+      const int r = e / LPR, t = fr0 + r;
+      const int tc = t < 0 ? 0 : (t > Tn - 1 ? Tn - 1 : t);
+      const char* ptr = reinterpret_cast<const char*>(d.x) + ((size_t)(tl.seq_begin + tc) * d.ldx) * (IOB ? 2 : 4) + (e % LPR) * 128;
+      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)ptr, (void __attribute__((address_space(3)))*)cst_dump, 4, 0, 0);
+    }
+  };
+
   load_slab(0);
   store_slab(0);
 
   f32x16 acc[TN];
+
+  // matrix-core snake: a lane's channel is the same in every tile and both sweeps: e^alpha / 2 pi and 1 / (e^beta + 1e-9) once
+  // (C <= 64: through LDS, four registers less across the tile loop; C = 128: in registers, no LDS left)
+  float er1 = 0.0f, ib1 = 0.0f, er2 = 0.0f, ib2 = 0.0f;
+  if (MFIR && snake) {
+    if constexpr (FIR_LDS) {
+      if (tid < C) {
+        cst_snk[tid] = expf(d.alpha1[tid]) * 0.15915494309189535f;
+        cst_snk[C + tid] = 1.0f / (expf(d.beta1[tid]) + 1e-9f);
+        cst_snk[2 * C + tid] = expf(d.alpha2[tid]) * 0.15915494309189535f;
+        cst_snk[3 * C + tid] = 1.0f / (expf(d.beta2[tid]) + 1e-9f);
+      }
+    } else {
+      const int chn = (wave % (C / 16)) * 16 + (lane & 15);
+      er1 = expf(d.alpha1[chn]) * 0.15915494309189535f;
+      ib1 = 1.0f / (expf(d.beta1[chn]) + 1e-9f);
+      er2 = expf(d.alpha2[chn]) * 0.15915494309189535f;
+      ib2 = 1.0f / (expf(d.beta2[chn]) + 1e-9f);
+    }
+  }
+
+  const int tid_prologue = tid;
+  for (;;) {
+  // Everything a lane derives from its index (LDS addresses of every fragment, row / channel predicates ...) is the same in
+  // every tile; hoisted out of this loop it would occupy a few hundred registers.  An opaque copy of the thread index per
+  // iteration keeps those values where they are used.
+  // The same holds between the phases of one tile: each section below derives its own copies, so that the fragment addresses
+  // of conv1 are not kept alive through the sweeps and conv2 (and vice versa).
+#define RB_LANE_IDS(n_)                      \
+  int tid_opaque##n_ = tid_prologue;         \
+  asm volatile("" : "+v"(tid_opaque##n_));   \
+  const int tid = tid_opaque##n_, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lk = lane >> 5; \
+  (void)lrow; (void)lk; (void)wave
+  RB_LANE_IDS(1);
+  bool ticket_drawn = false;
+  const int T = tile.seq_end - tile.seq_begin;
+  const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
+  RB_STAMP(0);
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-
-  float f[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) f[k] = snake ? d.filt[k] : 0.0f;
-  float al2 = 0.0f, be2 = 0.0f;  // second snake's parameters of this lane's channel (matrix-core snake: fetched with the first one's)
 
   // ------------------------------------------------------------------ conv1 over act1(x)
   int step = 0;
@@ -236,65 +391,26 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     if (MFIR && snake) {
       if constexpr (MFIR) {
         // raw x (as fp16, zero outside the utterance) into the whole image, then both FIR filters of act1 on the matrix cores, in place
-        // (16-bit x: every load of the image is in flight before the first one is consumed - one memory round trip, not two or three)
-        constexpr int Q8 = C / 8, PER = IOB ? (C == 128 ? 11 : (C == 64 ? 6 : 3)) : 4;
-        const int total = img_rows * Q8;
+        for (int base = tid; base < img_units; base += RB_THREADS * PERX) {
+          if (!XPF || base != tid) stage_issue(tile, base);
+          if (!ticket_drawn) {  // the next tile's ticket: asked for behind the image loads (returns come in order), used after conv1
+            ticket_drawn = true;
+            if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);
+          }
+          stage_commit(tile, base);
+        }
         constexpr int CB = C / 16, SEG = 8 / CB;
         const int cb = wave % CB, seg = wave / CB;
-        const int chn = cb * 16 + (lane & 15);
-        const float al1 = d.alpha1[chn], be1 = d.beta1[chn];  // (issued ahead of the image loads; consumed after them)
-        al2 = d.alpha2[chn];
-        be2 = d.beta2[chn];
-        for (int base = tid; base < total; base += RB_THREADS * PER) {
-          uint4 v[PER], v2[PER];
-#pragma unroll
-          for (int p = 0; p < PER; ++p) {
-            int e = base + p * RB_THREADS;
-            e = e < total ? e : total - 1;
-            const int r = e / Q8, c8 = (e % Q8) * 8;
-            int t = wbase - PADR + r;
-            if (r >= win_rows + 2 * PADR) t = -1;  // surplus rows behind the window: zeros
-            const int tc = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
-            if constexpr (IOB) {
-              v[p] = *reinterpret_cast<const uint4*>(xh + (size_t)(tile.seq_begin + tc) * d.ldx + c8);
-            } else {
-              v[p] = *reinterpret_cast<const uint4*>(d.x + (size_t)(tile.seq_begin + tc) * d.ldx + c8);
-              v2[p] = *reinterpret_cast<const uint4*>(d.x + (size_t)(tile.seq_begin + tc) * d.ldx + c8 + 4);
-            }
-            if (t < 0 || t >= T) { v[p] = make_uint4(0, 0, 0, 0); v2[p] = make_uint4(0, 0, 0, 0); }
-          }
-#pragma unroll
-          for (int p = 0; p < PER; ++p) {
-            const int e = base + p * RB_THREADS;
-            if (e >= total) continue;
-            const int r = e / Q8, c8 = (e % Q8) * 8;
-            uint4 o;
-            if constexpr (IOB && F16) {
-              o = v[p];
-            } else if constexpr (IOB) {  // bf16 -> fp16 (exact for |x| in fp16's range)
-              const unsigned int w4[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
-              unsigned int o4[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o4[q] = pack16<true>(bf16_to_f32(w4[q] & 0xFFFF), bf16_to_f32(w4[q] >> 16));
-              o = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-            } else {
-              auto f = [](unsigned int b) { return __builtin_bit_cast(float, b); };
-              o = make_uint4(pack16<true>(f(v[p].x), f(v[p].y)), pack16<true>(f(v[p].z), f(v[p].w)),
-                             pack16<true>(f(v2[p].x), f(v2[p].y)), pack16<true>(f(v2[p].z), f(v2[p].w)));
-            }
-            *reinterpret_cast<uint4*>(img + r * XP + c8) = o;
-          }
-        }
         const int tiles_total = (win_rows + 15) / 16;
         const int t_lo = seg * tiles_total / SEG, t_hi = (seg + 1) * tiles_total / SEG;
         SnakeFir fir;
         fir.img = img; fir.pitch = XP;
         fir.frame0 = wbase - PADR; fir.T = T; fir.ch0 = cb * 16;
         fir.row_begin = __builtin_amdgcn_readfirstlane(16 * t_lo); fir.n_tiles = __builtin_amdgcn_readfirstlane(t_hi - t_lo);
-        fir.er = expf(al1) * 0.15915494309189535f;
-        fir.inv_b = 1.0f / (expf(be1) + 1e-9f);
         RB_STAMP(1);
         __syncthreads();
+        fir.er = FIR_LDS ? cst_snk[cb * 16 + (lane & 15)] : er1;
+        fir.inv_b = FIR_LDS ? cst_snk[C + cb * 16 + (lane & 15)] : ib1;
         FirTaps ft;
 #pragma unroll
         for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
@@ -393,6 +509,10 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         }
       }
     }
+    if (!ticket_drawn) {
+      ticket_drawn = true;
+      if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);
+    }
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       __syncthreads();
       load_slab(step + 1);  // step + 1 < total_steps always holds here (conv2 follows)
@@ -414,7 +534,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   }
 
+  if (tid == 0) cst_ticket[0] = tile_of_ticket(ticket_raw);  // (read by everyone behind the next barriers)
   // ------------------------------------------------------------------ t1 = conv1 + bias (LeakyReLU applied here), bf16 in LDS
+  int next_tile = -1;
+  bool has_next = false;
+  TtsTile tile_next = tile;
+  {
+  RB_LANE_IDS(2);
   // t1 row i <-> local frame l0 - LEAD + i
   RB_STAMP(4);
   __syncthreads();  // every wave is done reading xa (t1 overlays it)
@@ -448,6 +574,10 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   }
   __syncthreads();
   RB_STAMP(5);
+  next_tile = __builtin_amdgcn_readfirstlane(cst_ticket[0]);
+  has_next = next_tile >= 0;
+  tile_next = load_tile(has_next ? next_tile : cur_tile);
+  if (L2PF && snake && has_next) l2_prefetch(tile_next, tid);
   if (MFIR && snake) {
     if constexpr (MFIR) {
       // act2 in place on t1 (rows [0, M1) of the window; the 6 rows on either side only feed outputs conv2 never reads)
@@ -458,8 +588,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       fir.img = img; fir.pitch = TP;  // (rows past M1 + 12 still hold act1(x): finite)
       fir.frame0 = l0 - RB_LEAD - PADR; fir.T = T; fir.ch0 = cb * 16;
       fir.row_begin = __builtin_amdgcn_readfirstlane(16 * (seg * tiles_total / SEG)); fir.n_tiles = tiles_total / SEG;
-      fir.er = expf(al2) * 0.15915494309189535f;
-      fir.inv_b = 1.0f / (expf(be2) + 1e-9f);
+      fir.er = FIR_LDS ? cst_snk[2 * C + cb * 16 + (lane & 15)] : er2;
+      fir.inv_b = FIR_LDS ? cst_snk[3 * C + cb * 16 + (lane & 15)] : ib2;
       FirTaps ft;
 #pragma unroll
       for (int k = 0; k < 12; ++k) ft.v[k] = f[k];
@@ -526,7 +656,10 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   }
 
+  }
   // ------------------------------------------------------------------ conv2 (dilation 1) over t1; output row o <-> t1 row LEAD + o
+  {
+  RB_LANE_IDS(3);
   // 16-bit x: the residual of this lane's output row is fetched now and waits in registers while conv2 runs (its latency is
   // paid beside the MFMAs, not in the epilogue)
   constexpr bool PREFETCH_RES = IOB && C <= 128;
@@ -541,11 +674,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         for (int rq = 0; rq < 4; ++rq) xres[j][rq] = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + j * 32 + 8 * rq + 4 * lk);
     }
   }
+  if (XPF && snake && has_next) stage_issue(tile_next, tid);  // the next tile's image: in flight while conv2 and the epilogue run
   for (int ch = 0; ch < NCH; ++ch) {
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       __syncthreads();
-      const bool more = step + 1 < total_steps;
-      if (more) load_slab(step + 1);
+      // (after the last step the ring's buffer 0 is free again: the next tile's first slab goes there)
+      const bool more = step + 1 < total_steps || has_next;
+      if (more) load_slab(step + 1 < total_steps ? step + 1 : 0);
       if (wave < RB_BM / 32) {
         const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
         for (int tt = 0; tt < nt; ++tt) {
@@ -566,6 +701,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   }
 
+  if (has_next) __syncthreads();  // every wavefront is done reading t1 and the slab ring: the next tile's image may overwrite them
   RB_STAMP(8);
   // ------------------------------------------------------------------ epilogue
   // transposed accumulators again: lane = output row, registers = groups of four consecutive channels.  Residual read, scaling,
@@ -623,10 +759,23 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   }
 #ifdef RB_DIAG_CLOCK
   RB_STAMP(9);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) phase_sum[k] += stamp[k + 1] - stamp[k];
+  ++n_iter;
+#endif
+  }
+  if (!has_next) break;
+  tile = tile_next;
+  cur_tile = next_tile;
+  }  // tiles of this workgroup
+#undef RB_LANE_IDS
+  retire(tid_prologue);
+#ifdef RB_DIAG_CLOCK
   if (MFIR && snake && tid == 64 * (RB_DIAG_CLOCK + 0)) {
     if (blockIdx.x < RB_TRACE_MAX) {
 #pragma unroll
-      for (int k = 0; k < 10; ++k) g_rb_trace[blockIdx.x][k] = stamp[k];
+      for (int k = 0; k < 9; ++k) g_rb_trace[blockIdx.x][k] = phase_sum[k];
+      g_rb_trace[blockIdx.x][9] = n_iter;
       g_rb_trace[blockIdx.x][10] = rt0;
       g_rb_trace[blockIdx.x][11] = __builtin_amdgcn_s_memrealtime();
       g_rb_trace[blockIdx.x][12] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -654,7 +803,7 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
   const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
   const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
-  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 : 0);
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + (MFIR ? 256 : 0) + 16;
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
@@ -662,7 +811,21 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
     set_error("resblock_step: raising the dynamic LDS limit failed");
     return TTS_E_LAUNCH;
   }
-  hipLaunchKernelGGL(k, dim3(d.n_tiles), dim3(RB_THREADS), lds, st, d);
+  // persistent grid: as many workgroups as the device keeps resident at this LDS size (rounded up to whole rounds of the 8 XCDs),
+  // never more than tiles
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), RB_THREADS, lds) != hipSuccess || cus < 1 || per_cu < 1) {
+    set_error("resblock_step: occupancy query failed");
+    return TTS_E_LAUNCH;
+  }
+  static const int fixed_per_cu = std::getenv("TOUCAN_RB_WG_PER_CU") ? std::atoi(std::getenv("TOUCAN_RB_WG_PER_CU")) : 0;  // (A/B runs)
+  if (fixed_per_cu > 0) per_cu = fixed_per_cu;
+  const long resident = (long)cus * per_cu;
+  const int grid = (int)(fixed_per_cu < 0 || d.n_tiles < resident ? d.n_tiles : resident);  // (TOUCAN_RB_WG_PER_CU=-1: one workgroup per tile)
+  static std::atomic<unsigned int> launches{0};
+  const int queue_slot = (int)(launches.fetch_add(1, std::memory_order_relaxed) % RB_QUEUE_SLOTS);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(RB_THREADS), lds, st, d, queue_slot);
   return launch_status("resblock_step");
 }
 

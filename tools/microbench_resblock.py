@@ -64,20 +64,19 @@ def main():
                 torch.cuda.synchronize()
                 us = 1e3 * e0.elapsed_time(e1) / args.reps
                 if trace is not None and name == "snake":  # (diagnostic library built with -DRB_DIAG_CLOCK=<wave>)
-                    nwg = min(40000, -(-rows // tile_rows) * args.batch)
+                    nwg = min(40000, -(-rows // tile_rows) * args.batch, int(os.environ.get('RB_TRACE_WGS', '256' if C == 128 else '512')))
                     tb = np.zeros((nwg, 16), dtype=np.uint64)
                     assert trace(tb.ctypes.data, nwg) == nwg
                     if args.dump:
                         os.makedirs(args.dump, exist_ok=True)
                         np.save(os.path.join(args.dump, f"trace_C{C}_k{k}.npy"), tb)
-                    st = tb[:, :10].astype(np.int64)
-                    ph = np.diff(st, axis=1)
+                    ph = tb[:, :9].astype(np.float64) / np.maximum(1, tb[:, 9:10].astype(np.float64))  # cycles per tile, per workgroup
                     names = ("stage", "sync+begin", "sweep1", "conv1", "t1", "begin2", "sweep2", "conv2", "epilogue")
-                    print("      phases (median cycles): " + "  ".join(f"{nm} {np.median(ph[:, i]):.0f}" for i, nm in enumerate(names))
-                          + f"  | total {np.median(st[:, 9] - st[:, 0]):.0f}", flush=True)
+                    print("      phases (median cycles per tile): " + "  ".join(f"{nm} {np.median(ph[:, i]):.0f}" for i, nm in enumerate(names))
+                          + f"  | total {np.median(ph.sum(axis=1)):.0f}; tiles per workgroup {tb[:, 9].min()}..{tb[:, 9].max()}", flush=True)
                     t0, t1_, hw = tb[:, 10].astype(np.int64), tb[:, 11].astype(np.int64), tb[:, 12]
                     dur = (t1_ - t0) * 10e-3  # us (100 MHz ticks)
-                    ghz = (st[:, 9] - st[:, 0]).sum() / ((t1_ - t0).sum() * 10.0)
+                    ghz = tb[:, :9].astype(np.float64).sum() / ((t1_ - t0).sum() * 10.0)
                     key = (hw >> np.uint64(32)) * np.uint64(1 << 16) + (hw & np.uint64(0xFF00))
                     cus = np.unique(key)
                     busy, span = [], []
@@ -88,6 +87,10 @@ def main():
                     print(f"      trace: {nwg} workgroups on {len(cus)} CUs; lifetime median {np.median(dur):.1f} us (min {dur.min():.1f}, max {dur.max():.1f}); "
                           f"shader clock {ghz:.2f} GHz; per CU: span {np.mean(span):.0f} us, lifetimes {np.mean(busy):.0f} us "
                           f"(= {np.mean(busy) / np.mean(span):.2f} resident); launch span {(t1_.max() - t0.min()) * 10e-3:.0f} us", flush=True)
+                    xcc = (hw >> np.uint64(32)).astype(np.int64) & 15
+                    print("      per XCD (tiles per workgroup mean | first start, last end in us after the launch's first start): "
+                          + "  ".join(f"{x}: {tb[xcc == x, 9].astype(np.float64).mean():.1f} | {(t0[xcc == x].min() - t0.min()) * 10e-3:.0f}, {(t1_[xcc == x].max() - t0.min()) * 10e-3:.0f}"
+                                      for x in np.unique(xcc)), flush=True)
                 flops = 2 * 2.0 * R * C * C * k
                 print(f"{C:>4} {k:>3} {dil:>3} {name:>6} {us:9.1f} {flops / us / 1e6:8.1f} {2.0 * R * C * 4 / 1e9 / (us * 1e-6):9.0f}", flush=True)
 
