@@ -19,6 +19,7 @@
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 
 #include "common.h"
@@ -38,6 +39,11 @@ namespace tts {
 #define RB_C64_TPS 1        // taps per weight slab at C = 64 (tuning knob)
 #endif
 constexpr int RB_LEAD = 16;
+
+// Workgroup barrier of this kernel: LDS traffic of the wavefront has landed (lgkmcnt), then s_barrier.  __syncthreads() also drains
+// every global load in flight (vmcnt(0)) - here that would be the next tile's image, the residual and the next weight slab, all
+// issued early on purpose.  Loads into registers are waited for where they are used; the kernel never reads back what it stored.
+__device__ __forceinline__ void rb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Work queues of the persistent tile loop: one 16-word slot per launch in flight (zero when a launch starts; its last workgroup
 // leaves it zero again).  Launches take slots round-robin; two launches could only share a slot if RB_QUEUE_SLOTS launches
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   float* cst_snk = cst_b2 + C;                                              // [4][C]: e^a1 / 2 pi, 1 / (e^b1 + 1e-9), same for the second snake (FIR_LDS)
   uint4* cst_fir = reinterpret_cast<uint4*>(cst_snk + (MFIR && C < 128 ? 4 * C : 0));  // [256] (FIR_LDS && snake)
   unsigned char* cst_dump = reinterpret_cast<unsigned char*>(cst_fir + (MFIR && C < 128 ? 256 : 0));  // [256 B] (L2PF: see l2_prefetch)
-  int* cst_ticket = reinterpret_cast<int*>(cst_dump + (MFIR ? 256 : 0));                             // [4] the next tile of this workgroup
+  int* cst_ticket = reinterpret_cast<int*>(cst_dump + (MFIR ? 256 : 0));                             // [8] the next tile of this workgroup: index, -, -, -, its table entry
   unsigned int ticket_raw = 0;
   float f[12];  // (scalar loads: ahead of the first atomic)
 #pragma unroll
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   };
   if (tid == 0) cst_ticket[0] = tile_of_ticket(ticket_raw);
-  __syncthreads();
+  rb_barrier();
   int cur_tile = __builtin_amdgcn_readfirstlane(cst_ticket[0]);
   if (cur_tile < 0) {  // (more workgroups than tiles)
     retire(tid);
@@ -320,17 +326,23 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   }
   TtsTile tile = load_tile(cur_tile);
   if (XPF && snake) stage_issue(tile, tid);
-  // one 4-byte load per 128-byte line of the next tile's image, result never used: the line is in this XCD's L2 when the tile
-  // starts.  The loads go global -> LDS (a 256-byte dump area all wavefronts share): no destination register that would have to
-  // stay reserved while they are in flight, and the compiler counts them like any other load.
-  auto l2_prefetch = [&](const TtsTile& tl, int tid_) __attribute__((always_inline)) {
-    constexpr int ROW_BYTES = C * (IOB ? 2 : 4), LPR = (ROW_BYTES + 127) / 128;
+  // one 4-byte load per 128-byte line of the next tile's image: the line is in this XCD's L2 when the tile starts.  Ordinary
+  // loads into NPF registers that stay allocated until conv2 is over, where a dummy use retires them - the compiler
+  // tracks them like any load.  (A global -> LDS load needs no register, but every later LDS access then waits for it: measured
+  // 2.5 k cycles at the next ds_read.)  Issued unconditionally (without a next tile: the current one's lines) - a value defined
+  // on one side of a branch only is what the register allocator spills first.
+  constexpr int L2_ROW_BYTES = C * (IOB ? 2 : 4), L2_LPR = (L2_ROW_BYTES + 127) / 128, NPF = L2PF ? L2_LPR : 1;
+  auto l2_prefetch = [&](const TtsTile& tl, int tid_, unsigned int (&sink)[NPF]) __attribute__((always_inline)) {
     const int Tn = tl.seq_end - tl.seq_begin, fr0 = tl.row0 - tl.seq_begin - RB_LEAD - h1 - PADR;
-    for (int e = tid_; e < (win_rows + 2 * PADR) * LPR; e += RB_THREADS) {
-      const int r = e / LPR, t = fr0 + r;
+    const int n_lines = (win_rows + 2 * PADR) * L2_LPR;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      int e = tid_ + k * RB_THREADS;
+      e = e < n_lines ? e : n_lines - 1;
+      const int t = fr0 + e / L2_LPR;
       const int tc = t < 0 ? 0 : (t > Tn - 1 ? Tn - 1 : t);
-      const char* ptr = reinterpret_cast<const char*>(d.x) + ((size_t)(tl.seq_begin + tc) * d.ldx) * (IOB ? 2 : 4) + (e % LPR) * 128;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)ptr, (void __attribute__((address_space(3)))*)cst_dump, 4, 0, 0);
+      const char* ptr = reinterpret_cast<const char*>(d.x) + ((size_t)(tl.seq_begin + tc) * d.ldx) * (IOB ? 2 : 4) + (e % L2_LPR) * 128;
+      sink[k] = *reinterpret_cast<const unsigned int*>(ptr);  // (not volatile: a volatile load is followed by vmcnt(0); the dummy use keeps it)
     }
   };
 
@@ -373,6 +385,15 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   (void)lrow; (void)lk; (void)wave
   RB_LANE_IDS(1);
   bool ticket_drawn = false;
+  int next_resolved = -1;
+  int4 next_entry = make_int4(0, 0, 0, 0);
+  if (!(MFIR && snake)) {  // (the matrix-core snake path draws behind its image loads, below)
+    ticket_drawn = true;
+    if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);
+  }
+  unsigned int pf_sink[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) pf_sink[k] = 0;
   const int T = tile.seq_end - tile.seq_begin;
   const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
   RB_STAMP(0);
@@ -385,7 +406,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   int step = 0;
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * KC;
-    if (ch > 0) __syncthreads();
+    if (ch > 0) rb_barrier();
     // window row j <-> local frame l0 - LEAD - h1 + j
     const int wbase = l0 - RB_LEAD - h1;
     if (MFIR && snake) {
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         fir.frame0 = wbase - PADR; fir.T = T; fir.ch0 = cb * 16;
         fir.row_begin = __builtin_amdgcn_readfirstlane(16 * t_lo); fir.n_tiles = __builtin_amdgcn_readfirstlane(t_hi - t_lo);
         RB_STAMP(1);
-        __syncthreads();
+        rb_barrier();
         fir.er = FIR_LDS ? cst_snk[cb * 16 + (lane & 15)] : er1;
         fir.inv_b = FIR_LDS ? cst_snk[C + cb * 16 + (lane & 15)] : ib1;
         FirTaps ft;
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         if constexpr (FIR_LDS) fir.load_constants(cst_fir, lane);
         else fir.copy_constants(fir_const);
         fir.begin(lane);
-        __syncthreads();
+        rb_barrier();
         RB_STAMP(2);
         fir.template sweep<F16>(ft, lane);
         RB_STAMP(3);
@@ -509,12 +530,15 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
         }
       }
     }
-    if (!ticket_drawn) {
-      ticket_drawn = true;
-      if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);
+    if (ch == 0) {
+      // the ticket is back (it was drawn ahead of this tile's image loads, and returns come in order): the tile entry it
+      // stands for is fetched now and published after conv1 - no wavefront ever waits for either.  (Every lane computes it - only
+      // thread 0 drew a ticket, the others resolve ticket 0 - so that nothing here is defined on one side of a branch.)
+      next_resolved = tile_of_ticket(ticket_raw);
+      next_entry = *reinterpret_cast<const int4*>(d.tiles + (next_resolved >= 0 ? next_resolved : cur_tile));
     }
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
-      __syncthreads();
+      rb_barrier();
       load_slab(step + 1);  // step + 1 < total_steps always holds here (conv2 follows)
       const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
       for (int tt = 0; tt < nt; ++tt) {
@@ -534,7 +558,10 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   }
 
-  if (tid == 0) cst_ticket[0] = tile_of_ticket(ticket_raw);  // (read by everyone behind the next barriers)
+  if (tid == 0) {  // (read by everyone behind the next barriers)
+    cst_ticket[0] = next_resolved;
+    *reinterpret_cast<int4*>(cst_ticket + 4) = next_entry;
+  }
   // ------------------------------------------------------------------ t1 = conv1 + bias (LeakyReLU applied here), bf16 in LDS
   int next_tile = -1;
   bool has_next = false;
@@ -543,7 +570,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   RB_LANE_IDS(2);
   // t1 row i <-> local frame l0 - LEAD + i
   RB_STAMP(4);
-  __syncthreads();  // every wave is done reading xa (t1 overlays it)
+  rb_barrier();  // every wave is done reading xa (t1 overlays it)
   {
     // Both convs run transposed (weights as the A operand): a lane owns ONE frame and its accumulator registers hold four
     // consecutive output channels per group of four - a 16-bit quadruple is one 8-byte LDS store, and "outside the utterance"
@@ -572,12 +599,20 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       }
     }
   }
-  __syncthreads();
+  rb_barrier();
   RB_STAMP(5);
   next_tile = __builtin_amdgcn_readfirstlane(cst_ticket[0]);
   has_next = next_tile >= 0;
-  tile_next = load_tile(has_next ? next_tile : cur_tile);
-  if (L2PF && snake && has_next) l2_prefetch(tile_next, tid);
+  {
+    const int4 e = *reinterpret_cast<const int4*>(cst_ticket + 4);
+    tile_next.row0 = __builtin_amdgcn_readfirstlane(e.x);
+    tile_next.seq_begin = __builtin_amdgcn_readfirstlane(e.y);
+    tile_next.seq_end = __builtin_amdgcn_readfirstlane(e.z);
+    tile_next.seq_id = __builtin_amdgcn_readfirstlane(e.w);
+  }
+  if constexpr (L2PF) {
+    if (snake) l2_prefetch(tile_next, tid, pf_sink);
+  }
   if (MFIR && snake) {
     if constexpr (MFIR) {
       // act2 in place on t1 (rows [0, M1) of the window; the 6 rows on either side only feed outputs conv2 never reads)
@@ -597,7 +632,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       if constexpr (FIR_LDS) fir.load_constants(cst_fir, lane);
       else fir.copy_constants(fir_const);
       fir.begin(lane);
-      __syncthreads();
+      rb_barrier();
       RB_STAMP(6);
       fir.template sweep<F16>(ft, lane);
       RB_STAMP(7);
@@ -620,7 +655,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       } else {
         for (int i = 0; i < RB_M1; ++i) t1[i * TP + chn] = 0;
       }
-      __syncthreads();
+      rb_barrier();
     } else {
       // in place on t1: every thread first computes all its outputs into registers, then overwrites.
       // item = (8*NCH2 rows, channel): 256 rows x C channels over 512 threads = C/2 values per thread
@@ -645,7 +680,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
                              1.0f / (expf(d.beta2[chn]) + 1e-9f));
         }
       }
-      __syncthreads();
+      rb_barrier();
 #pragma unroll
       for (int q = 0; q < ITEMS; ++q) {
         const int it = tid + q * RB_THREADS;
@@ -660,48 +695,58 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   // ------------------------------------------------------------------ conv2 (dilation 1) over t1; output row o <-> t1 row LEAD + o
   {
   RB_LANE_IDS(3);
-  // 16-bit x: the residual of this lane's output row is fetched now and waits in registers while conv2 runs (its latency is
-  // paid beside the MFMAs, not in the epilogue)
+  // 16-bit x: the residual of this lane's output row is fetched in conv2's first step and waits in registers while conv2 runs
+  // (its latency is paid beside the MFMAs, not in the epilogue).  It - and at C = 128 the next tile's image - is issued BEHIND the
+  // first step's weight-slab load: loads return in order, so the slab's wait then lets them stay in flight, and the next slab's
+  // wait a whole step later finds them done.
   constexpr bool PREFETCH_RES = IOB && C <= 128;
   uint2 xres[PREFETCH_RES ? TN : 1][4];
-  if constexpr (PREFETCH_RES) {
-    if (wave < RB_BM / 32) {
-      int row = tile.row0 + wave * 32 + lrow;
-      row = row < tile.seq_end ? row : tile.seq_end - 1;
+  // (the first step is peeled - not a flag inside the loop: a value defined on one side of a branch only is what the register
+  // allocator spills first; for the same reason every wavefront fetches a residual, also the one without output rows)
+  auto conv2_step = [&](auto first, int ch, int tap0) __attribute__((always_inline)) {
+    rb_barrier();
+    // (after the last step the ring's buffer 0 is free again: the next tile's first slab goes there)
+    const bool more = step + 1 < total_steps || has_next;
+    if (more) load_slab(step + 1 < total_steps ? step + 1 : 0);
+    if constexpr (decltype(first)::value) {
+      if constexpr (PREFETCH_RES) {
+        int row = tile.row0 + (wave < RB_BM / 32 ? wave : 0) * 32 + lrow;
+        row = row < tile.seq_end ? row : tile.seq_end - 1;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) xres[j][rq] = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + j * 32 + 8 * rq + 4 * lk);
+          for (int rq = 0; rq < 4; ++rq) xres[j][rq] = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + j * 32 + 8 * rq + 4 * lk);
+      }
+      if (XPF && snake && has_next) stage_issue(tile_next, tid);  // the next tile's image: in flight while conv2 and the epilogue run
     }
-  }
-  if (XPF && snake && has_next) stage_issue(tile_next, tid);  // the next tile's image: in flight while conv2 and the epilogue run
-  for (int ch = 0; ch < NCH; ++ch) {
-    for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
-      __syncthreads();
-      // (after the last step the ring's buffer 0 is free again: the next tile's first slab goes there)
-      const bool more = step + 1 < total_steps || has_next;
-      if (more) load_slab(step + 1 < total_steps ? step + 1 : 0);
-      if (wave < RB_BM / 32) {
-        const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
-        for (int tt = 0; tt < nt; ++tt) {
-          const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
-          const int tap = tap0 + tt;
+    if (wave < RB_BM / 32) {
+      const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
+      for (int tt = 0; tt < nt; ++tt) {
+        const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
+        const int tap = tap0 + tt;
 #pragma unroll
-          for (int ks = 0; ks < KC / 16; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + ks * 16 + lk * 8);
+        for (int ks = 0; ks < KC / 16; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + ks * 16 + lk * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-              acc[j] = mfma16<F16>(b, a, acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
-            }
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
+            acc[j] = mfma16<F16>(b, a, acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
           }
         }
       }
-      if (more) store_slab((step + 1) & 1);
     }
-  }
+    if (more) store_slab((step + 1) & 1);
+    ++step;
+  };
+  conv2_step(std::true_type{}, 0, 0);
+  for (int ch = 0; ch < NCH; ++ch)
+    for (int tap0 = ch == 0 ? TPS : 0; tap0 < d.taps; tap0 += TPS) conv2_step(std::false_type{}, ch, tap0);
 
-  if (has_next) __syncthreads();  // every wavefront is done reading t1 and the slab ring: the next tile's image may overwrite them
+  if (has_next) rb_barrier();  // every wavefront is done reading t1 and the slab ring: the next tile's image may overwrite them
+  if constexpr (L2PF) {
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) asm volatile("" ::"v"(pf_sink[k]));  // (the L2 prefetch loads retire here)
+  }
   RB_STAMP(8);
   // ------------------------------------------------------------------ epilogue
   // transposed accumulators again: lane = output row, registers = groups of four consecutive channels.  Residual read, scaling,
@@ -753,6 +798,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
             }
             *yp = make_float4(v[0], v[1], v[2], v[3]);
           }
+          // one row piece at a time: interleaved, the eight pieces' temporaries (~80 registers beside the accumulators and the
+          // prefetched residual) are what pushed the C = 64 instantiation over its 128 registers
+          if constexpr (PREFETCH_RES) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -803,7 +851,7 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
   const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
   const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
-  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + (MFIR ? 256 : 0) + 16;
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + (MFIR ? 256 : 0) + 32;
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
