@@ -74,6 +74,19 @@ class TtsWavenetDesc(C.Structure):
     ]
 
 
+class TtsFfnDesc(C.Structure):
+    _fields_ = [
+        ("x", _p), ("ldx", _i),
+        ("y", _p), ("ldy", _i),
+        ("rows", _i), ("channels", _i),
+        ("ln_g", _p), ("ln_b", _p),
+        ("w", _p), ("b2", _p),
+        ("post_g", _p), ("post_b", _p),
+        ("hidden", _i), ("compute", _i),
+        ("alpha", _f), ("eps", _f),
+    ]
+
+
 class TtsConfig(C.Structure):
     _fields_ = [("multilingual", _i), ("multispeaker", _i), ("vocoder", _i), ("precision", _i), ("small_tile_blocks", _i), ("post_bias", _f)]
 
@@ -92,6 +105,7 @@ PROTOTYPES = {
     "tts_resblock_tile_rows": (C.c_int, [_i]),
     "tts_snake_fir_table": (C.c_int, [_p, _p]),
     "tts_wavenet_layer": (C.c_int, [C.POINTER(TtsWavenetDesc), _p]),
+    "tts_ffn_fused": (C.c_int, [C.POINTER(TtsFfnDesc), _p]),
     "tts_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     "tts_cond_layernorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _p, _i, _i, _p]),
     "tts_cln_mlp_weight_floats": (C.c_int64, [_i, _i]),
@@ -139,7 +153,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 10  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 11  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

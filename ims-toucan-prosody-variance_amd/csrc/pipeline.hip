@@ -111,6 +111,7 @@ struct Handle {
   std::unordered_map<std::string, int*> bounds_cache;
   int small_tile_blocks = 1536;
   bool no_fused_wavenet = false;  // TOUCAN_NO_FUSED_WAVENET: A/B switch, same meaning as in engine.py
+  bool no_fused_ffn = false;      // TOUCAN_NO_FUSED_FFN: likewise
   // relative position tables [block][2 pmax - 1][192] of the two Conformer stacks, built from the uploaded sinusoid table
   float* ptab[2] = {nullptr, nullptr};
   int pmax = 0;
@@ -386,6 +387,7 @@ struct Block {
   const float *ln_g[5], *ln_b[5];  // norm_ff_macaron, norm_mha, norm_conv, norm_ff, norm_final
   ConvW ffm1, ffm2, qkv, out, pos, pw1, pw2, ff1, ff2;
   const float *u, *v, *dw_w, *dw_b;
+  const Dev *ffm_fused = nullptr, *ff_fused = nullptr;  // packing.pack_ffn (16-bit configurations, kernel size 1), or null
 };
 
 int block_of(const Handle* h, const std::string& p, Block* b) {
@@ -398,6 +400,8 @@ int block_of(const Handle* h, const std::string& p, Block* b) {
   TTS_TRY(conv_of(h, p + "ffm.w2", &b->ffm2));
   TTS_TRY(conv_of(h, p + "ff.w1", &b->ff1));
   TTS_TRY(conv_of(h, p + "ff.w2", &b->ff2));
+  b->ffm_fused = find(h, p + "ffm.fused");
+  b->ff_fused = find(h, p + "ff.fused");
   TTS_TRY(conv_of(h, p + "qkv", &b->qkv));
   TTS_TRY(conv_of(h, p + "out", &b->out));
   TTS_TRY(conv_of(h, p + "pos", &b->pos));
@@ -438,6 +442,29 @@ int ensure_ptabs(Handle* h, hipStream_t st) {
   return TTS_OK;
 }
 
+// One feed-forward module in one launch (tts_ffn_fused): x <- [LN_post](x + 0.5 FFN(LN(x)))
+int ffn_fused(Handle* h, const Dev* fused, const ConvW& w1, const ConvW& w2, const float* g, const float* b, const float* post_g, const float* post_b,
+              float* x, int R, hipStream_t st) {
+  TtsFfnDesc d;
+  memset(&d, 0, sizeof(d));
+  d.x = x; d.ldx = ATT; d.y = x; d.ldy = ATT; d.rows = R; d.channels = ATT;
+  d.ln_g = g; d.ln_b = b;
+  d.w = fused->p; d.b2 = w2.bias;
+  d.post_g = post_g; d.post_b = post_b;
+  d.hidden = (int)(fused->bytes / (28 * 1024)) * 32;
+  d.compute = w1.compute16; d.alpha = 0.5f; d.eps = 1e-12f;
+  if (h->prof_on) {
+    const char* name = d.compute == TTS_COMPUTE_F16 ? "ffn_fused_f16" : "ffn_fused_bf16";
+    if (prof_wants(h, name)) {
+      ProfRec* r = prof_open(h, name, 4.0 * R * ATT * d.hidden, (double)R * ATT * 8 + (double)fused->bytes, (double)R * ATT, st);
+      const int rc = tts_ffn_fused(&d, st);
+      (void)hipEventRecord(r->e1, st);
+      return rc;
+    }
+  }
+  return tts_ffn_fused(&d, st);
+}
+
 // Layers/EncoderLayer.py:62-144 x 6 on the residual stream x [rows, 192] (already scaled by sqrt(192))
 int conformer(Handle* h, int stack, float* x, const Layout& l, Arena& a, hipStream_t st) {
   const int R = l.total, kernel = stack ? 31 : 7;
@@ -464,9 +491,16 @@ int conformer(Handle* h, int stack, float* x, const Layout& l, Arena& a, hipStre
     half.alpha = 0.5f; half.res = T2(x, ATT);
     res1.res = T2(x, ATT);
     // Macaron feed-forward (EncoderLayer.py:84-90)
-    TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[0], b.ln_b[0], R, ATT, 1e-12f, st));
-    TTS_TRY(conv(h, b.ffm1, T2(ln, ATT), T2(hid, 1536, b16), l, st, relu));
-    TTS_TRY(conv(h, b.ffm2, T2(hid, 1536, b16), T2(x, ATT), l, st, half));
+    // (the same decision as engine.py: 16-bit configuration and packed weights loaded - not the number of rows: an utterance's
+    // result must not depend on the batch it is in)
+    const bool fuse_ffn = b16 == 16 && !h->no_fused_ffn;
+    if (fuse_ffn && b.ffm_fused) {
+      TTS_TRY(ffn_fused(h, b.ffm_fused, b.ffm1, b.ffm2, b.ln_g[0], b.ln_b[0], nullptr, nullptr, x, R, st));
+    } else {
+      TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[0], b.ln_b[0], R, ATT, 1e-12f, st));
+      TTS_TRY(conv(h, b.ffm1, T2(ln, ATT), T2(hid, 1536, b16), l, st, relu));
+      TTS_TRY(conv(h, b.ffm2, T2(hid, 1536, b16), T2(x, ATT), l, st, half));
+    }
     // relative-position self-attention (:93-116)
     TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[1], b.ln_b[1], R, ATT, 1e-12f, st));
     TTS_TRY(conv(h, b.qkv, T2(ln, ATT), T2(qkv, 3 * ATT), l, st));
@@ -478,10 +512,14 @@ int conformer(Handle* h, int stack, float* x, const Layout& l, Arena& a, hipStre
     TTS_TRY(tts_dwconv_swish(glu, ATT, dwo, ATT, b.dw_w, b.dw_b, ATT, kernel, t64.dev, t64.n, 64, st));
     TTS_TRY(conv(h, b.pw2, T2(dwo, ATT), T2(x, ATT), l, st, res1));
     // feed-forward (:128-133) and the block's final norm (:135-136)
-    TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[3], b.ln_b[3], R, ATT, 1e-12f, st));
-    TTS_TRY(conv(h, b.ff1, T2(ln, ATT), T2(hid, 1536, b16), l, st, relu));
-    TTS_TRY(conv(h, b.ff2, T2(hid, 1536, b16), T2(x, ATT), l, st, half));
-    TTS_TRY(tts_layernorm(x, ATT, x, ATT, b.ln_g[4], b.ln_b[4], R, ATT, 1e-12f, st));
+    if (fuse_ffn && b.ff_fused) {  // (with the block's final norm in its epilogue)
+      TTS_TRY(ffn_fused(h, b.ff_fused, b.ff1, b.ff2, b.ln_g[3], b.ln_b[3], b.ln_g[4], b.ln_b[4], x, R, st));
+    } else {
+      TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[3], b.ln_b[3], R, ATT, 1e-12f, st));
+      TTS_TRY(conv(h, b.ff1, T2(ln, ATT), T2(hid, 1536, b16), l, st, relu));
+      TTS_TRY(conv(h, b.ff2, T2(hid, 1536, b16), T2(x, ATT), l, st, half));
+      TTS_TRY(tts_layernorm(x, ATT, x, ATT, b.ln_g[4], b.ln_b[4], R, ATT, 1e-12f, st));
+    }
   }
   return TTS_OK;
 }
@@ -534,6 +572,7 @@ int pipeline_create(const TtsConfig* cfg, Handle** out) {
   h->cfg = *cfg;
   if (cfg->small_tile_blocks > 0) h->small_tile_blocks = cfg->small_tile_blocks;
   h->no_fused_wavenet = getenv("TOUCAN_NO_FUSED_WAVENET") != nullptr;
+  h->no_fused_ffn = getenv("TOUCAN_NO_FUSED_FFN") != nullptr;
   *out = h;
   return TTS_OK;
 }

@@ -160,7 +160,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   // split - so the split is dynamic).  Neighbouring tiles share their halo rows, so every XCD owns a contiguous run of tiles
   // (q + (x < r) of them, q = n / 8, r = n % 8: a bijection for every n) and a workgroup draws from the run of the XCD it really
   // runs on (XCC_ID register): the tiles in flight on an XCD at any moment are neighbours, and its private L2 serves the halo
-  // the neighbour already fetched.  (No stealing between runs: the XCDs get equal shares and run at equal speed.)
+  // the neighbour already fetched.  A workgroup whose own run is used up takes from the other XCDs' runs: nothing guarantees that
+  // every XCD hosts a workgroup (a grid smaller than 8, or a placement other than round-robin), so a run must never depend on
+  // its own XCD for being processed.
   // queue[x] = next ticket of XCD x's run, queue[8] = workgroups that are done; the last one to finish zeroes the slot again.
   unsigned int* queue = g_rb_queue[queue_slot];
   const int q8 = d.n_tiles >> 3, r8 = d.n_tiles & 7;
@@ -170,6 +172,18 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   // the tile a ticket of the own run stands for, -1 past the end of the run
   const int run_lo = run_lo_of(xcc), run_n = run_n_of(xcc);
   auto tile_of_ticket = [&](unsigned int ticket) __attribute__((always_inline)) { return ticket < (unsigned int)run_n ? run_lo + (int)ticket : -1; };
+  // (one thread, own run exhausted) a tile of another XCD's run, -1 when every run is used up
+  auto steal_tile = [&]() __attribute__((always_inline)) {
+    int found = -1;
+    for (int sft = 1; sft < 8 && found < 0; ++sft) {
+      const int x = (xcc + sft) & 7, n = run_n_of(x);
+      if (n > 0) {
+        const unsigned int t2 = atomicAdd(&queue[x], 1u);
+        if (t2 < (unsigned int)n) found = run_lo_of(x) + (int)t2;
+      }
+    }
+    return found;
+  };
   // (behind the queue's atomics the compiler no longer proves the tile table read-only and fetches entries with vector loads:
   // the values are wave-uniform, so they go back to scalar registers - every address below is built from them)
   auto load_tile = [&](int idx) __attribute__((always_inline)) {
@@ -317,7 +331,11 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       *reinterpret_cast<uint4*>(img + r * XP + c8) = o;
     }
   };
-  if (tid == 0) cst_ticket[0] = tile_of_ticket(ticket_raw);
+  if (tid == 0) {
+    int first = tile_of_ticket(ticket_raw);
+    if (first < 0) first = steal_tile();
+    cst_ticket[0] = first;
+  }
   rb_barrier();
   int cur_tile = __builtin_amdgcn_readfirstlane(cst_ticket[0]);
   if (cur_tile < 0) {  // (more workgroups than tiles)
@@ -535,6 +553,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       // stands for is fetched now and published after conv1 - no wavefront ever waits for either.  (Every lane computes it - only
       // thread 0 drew a ticket, the others resolve ticket 0 - so that nothing here is defined on one side of a branch.)
       next_resolved = tile_of_ticket(ticket_raw);
+      if (next_resolved < 0 && tid == 0) next_resolved = steal_tile();  // (rare: the end of this XCD's run)
       next_entry = *reinterpret_cast<const int4*>(d.tiles + (next_resolved >= 0 ? next_resolved : cur_tile));
     }
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {

@@ -179,6 +179,18 @@ class Ops:
         capi.check(self.lib.tts_wavenet_layer(C.byref(d), self.stream()), "tts_wavenet_layer")
         return hs_out
 
+    def ffn_fused(self, x, y, norm, fused, b2, rows, compute, post=None, alpha=0.5, eps=1e-12):
+        """Fused feed-forward module (tts_ffn_fused): y = [LN_post](x + alpha (W2 relu(W1 LN(x) + b1) + b2)); 16-bit modes, kernel size 1.
+        fused: packing.pack_ffn's tensor; norm / post: (gamma, beta)."""
+        d = capi.TtsFfnDesc()
+        d.x, d.ldx, d.y, d.ldy, d.rows, d.channels = x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), rows, x.shape[1]
+        d.ln_g, d.ln_b = norm[0].data_ptr(), norm[1].data_ptr()
+        d.w, d.b2 = fused.data_ptr(), b2.data_ptr()
+        d.post_g, d.post_b = (post[0].data_ptr(), post[1].data_ptr()) if post is not None else (None, None)
+        d.hidden, d.compute, d.alpha, d.eps = 32 * (fused.numel() // (14 * 1024)), compute, alpha, eps  # (28 KB of int16 per 32 hidden channels)
+        capi.check(self.lib.tts_ffn_fused(C.byref(d), self.stream()), "tts_ffn_fused")
+        return y
+
     def layernorm(self, x, y, gamma, beta, rows, c, eps=1e-12):
         capi.check(self.lib.tts_layernorm(x.data_ptr(), _ld(x), y.data_ptr(), _ld(y), gamma.data_ptr(), beta.data_ptr(), rows, c, eps,
                                           self.stream()), "tts_layernorm")
@@ -328,6 +340,10 @@ class ConformerWeights:
             for ff in ("feed_forward_macaron", "feed_forward"):
                 blk[ff + ".w1"] = pack(sd[p + ff + ".w_1.weight"], sd[p + ff + ".w_1.bias"], device)
                 blk[ff + ".w2"] = pack(sd[p + ff + ".w_2.weight"], sd[p + ff + ".w_2.bias"], device)
+                # 16-bit configurations, kernel size 1: the whole module is one launch (tts_ffn_fused) on weights in its fragment order
+                w1 = np.asarray(sd[p + ff + ".w_1.weight"])
+                if bf16 and not os.environ.get("TOUCAN_NO_FUSED_FFN") and (w1.ndim == 2 or w1.shape[2] == 1) and w1.shape[1] == ATT and w1.shape[0] % 32 == 0:
+                    blk[ff + ".fused"] = packing.pack_ffn(w1, sd[p + ff + ".w_1.bias"], sd[p + ff + ".w_2.weight"], device, "f16" if bf16 == "f16" else "bf16")
             a = p + "self_attn."
             wqkv = np.concatenate([sd[a + f"linear_{n}.weight"] for n in "qkv"], axis=0)
             bqkv = np.concatenate([sd[a + f"linear_{n}.bias"] for n in "qkv"], axis=0)
@@ -473,10 +489,16 @@ class AcousticEngine:
         glu = ops.empty(R, ATT)
         dwo = ops.empty(R, ATT)
         for li, blk in enumerate(cw.blocks):
-            for ff, norm in (("feed_forward_macaron", "norm_ff_macaron"),):
-                ops.layernorm(x, ln, *blk[norm], R, ATT)
-                ops.conv(blk[ff + ".w1"], ln, hid, rag, act=ACT_RELU)
-                ops.conv(blk[ff + ".w2"], hid, x, rag, alpha=0.5, res=x)
+            # (one launch per module whatever the number of rows: its time is flat at ~60 us - 48 dependent chunk steps - against 52 us
+            # of the unfused launches at 4 096 rows and 212 us at 20 480; a row-count threshold would make an utterance's result
+            # depend on the batch it is in)
+            if "feed_forward_macaron.fused" in blk:
+                ops.ffn_fused(x, x, blk["norm_ff_macaron"], blk["feed_forward_macaron.fused"], blk["feed_forward_macaron.w2"].bias, R,
+                              blk["feed_forward_macaron.w1"].compute16)
+            else:
+                ops.layernorm(x, ln, *blk["norm_ff_macaron"], R, ATT)
+                ops.conv(blk["feed_forward_macaron.w1"], ln, hid, rag, act=ACT_RELU)
+                ops.conv(blk["feed_forward_macaron.w2"], hid, x, rag, alpha=0.5, res=x)
             ops.layernorm(x, ln, *blk["norm_mha"], R, ATT)
             ops.conv(blk["qkv"], ln, qkv, rag)
             ops.attention(qkv, cw.ptabs[li], cw.pmax, blk["u"], blk["v"], ctx, rag)
@@ -485,10 +507,14 @@ class AcousticEngine:
             ops.conv(blk["pw1"], ln, glu, rag)
             ops.dwconv_swish(glu, dwo, blk["dw_w"], blk["dw_b"], ATT, cw.kernel, rag)
             ops.conv(blk["pw2"], dwo, x, rag, res=x)
-            ops.layernorm(x, ln, *blk["norm_ff"], R, ATT)
-            ops.conv(blk["feed_forward.w1"], ln, hid, rag, act=ACT_RELU)
-            ops.conv(blk["feed_forward.w2"], hid, x, rag, alpha=0.5, res=x)
-            ops.layernorm(x, x, *blk["norm_final"], R, ATT)
+            if "feed_forward.fused" in blk:  # (with the block's final norm in its epilogue)
+                ops.ffn_fused(x, x, blk["norm_ff"], blk["feed_forward.fused"], blk["feed_forward.w2"].bias, R, blk["feed_forward.w1"].compute16,
+                              post=blk["norm_final"])
+            else:
+                ops.layernorm(x, ln, *blk["norm_ff"], R, ATT)
+                ops.conv(blk["feed_forward.w1"], ln, hid, rag, act=ACT_RELU)
+                ops.conv(blk["feed_forward.w2"], hid, x, rag, alpha=0.5, res=x)
+                ops.layernorm(x, x, *blk["norm_final"], R, ATT)
             if taps is not None:
                 taps[f"{tap_name}_block{li}"] = x.clone()
         return x

@@ -64,6 +64,8 @@ class NativePipeline:
         t = t.detach().cpu().contiguous()
         if t.dtype == torch.int32:
             code, raw = 3, t.numpy()
+        elif t.dtype == torch.int16:  # (raw 16-bit patterns: a kernel's own fragment order, e.g. packing.pack_ffn)
+            code, raw = 1, t.numpy()
         else:
             code = _DT[t.dtype]
             raw = t.view(torch.int16).numpy() if t.dtype in (torch.bfloat16, torch.float16) else t.numpy()
@@ -95,6 +97,9 @@ class NativePipeline:
                 for src, dst in (("feed_forward_macaron.w1", "ffm.w1"), ("feed_forward_macaron.w2", "ffm.w2"), ("feed_forward.w1", "ff.w1"),
                                  ("feed_forward.w2", "ff.w2"), ("qkv", "qkv"), ("out", "out"), ("pos", "pos"), ("pw1", "pw1"), ("pw2", "pw2")):
                     self._conv(p + dst, blk[src])
+                for src, dst in (("feed_forward_macaron.fused", "ffm.fused"), ("feed_forward.fused", "ff.fused")):
+                    if src in blk:
+                        self._load(p + dst, blk[src])
                 for v in ("u", "v", "dw_w", "dw_b"):
                     self._load(p + v, blk[v])
         self._load("out_norm.g", ac.out_norm[0])

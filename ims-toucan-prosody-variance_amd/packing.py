@@ -108,6 +108,39 @@ def pack_conv(weight, bias, device, dil=1, mode=capi.MODE_LINEAR, bf16=False, sm
     return ConvWeights(w_kio, None if bias is None else _np(bias), mode, dil, (k - 1) // 2 * dil, device, bf16, small_only)
 
 
+def pack_ffn(w1, b1, w2, device, fmt):
+    """Both weight matrices and the first bias of a kernel-size-1 feed-forward module in tts_ffn_fused's fragment order
+    (include/toucan_tts.h): w1 = w_1.weight [hidden, 192(, 1)], b1 = w_1.bias, w2 = w_2.weight [192, hidden(, 1)]; fmt "bf16" /
+    "f16".  28 KB per 32 hidden channels, returned as a flat int16 tensor (the bias fragments are fp32 bit patterns)."""
+    w1, w2, b1 = _np(w1).astype(np.float32), _np(w2).astype(np.float32), _np(b1).astype(np.float32)
+    if w1.ndim == 3:
+        assert w1.shape[2] == 1 and w2.shape[2] == 1, "the fused feed-forward kernel covers kernel size 1"
+        w1, w2 = w1[:, :, 0], w2[:, :, 0]
+    hidden, c = w1.shape
+    assert c == 192 and w2.shape == (c, hidden) and b1.shape == (hidden,) and hidden % 32 == 0
+    n = hidden // 32
+    lane = np.arange(64)
+    lk, r = lane // 32, lane % 32
+    i = np.arange(8)
+    frag = np.zeros((n, 24, 64, 8), dtype=np.float32)
+    for ks in range(12):  # W1 fragment ks: [lane][i] = W1[32 c + r][16 ks + 8 lk + i]
+        cols = 16 * ks + 8 * lk[:, None] + i[None, :]
+        frag[:, ks] = w1.reshape(n, 32, c)[:, r[:, None], cols]
+    slot = np.where(i[None, :] < 4, 4 * lk[:, None] + i[None, :], 8 + 4 * lk[:, None] + i[None, :] - 4)  # [lane][i]
+    w2c = w2.reshape(c, n, 32)
+    for j in range(6):  # W2 fragment (j, ab): [lane][i] = W2[32 j + r][32 c + 16 ab + slot]
+        for ab in range(2):
+            frag[:, 12 + 2 * j + ab] = np.transpose(w2c[32 * j + r[:, None], :, 16 * ab + slot], (2, 0, 1))
+    dt = torch.float16 if fmt == "f16" else torch.bfloat16
+    w16 = torch.from_numpy(frag).to(dt).view(torch.int16).numpy()  # [n][24][64][8] 16-bit patterns
+    bias = np.zeros((n, 4, 64, 4), dtype=np.float32)  # b1 fragment q: [lane][4] = b1[32 c + 8 q + 4 lk + 0..3]
+    for q in range(4):
+        bias[:, q] = b1.reshape(n, 32)[:, 8 * q + 4 * lk[:, None] + np.arange(4)[None, :]]
+    out = np.concatenate([w16.reshape(n, -1), bias.view(np.int16).reshape(n, -1)], axis=1)  # [n][28 KB / 2]
+    assert out.shape[1] * 2 == 28 * 1024
+    return torch.from_numpy(np.ascontiguousarray(out).reshape(-1)).to(device)
+
+
 def pack_conv_transpose(weight, bias, stride, device, bf16=False):
     """ConvTranspose1d weight [cin, cout, k] with k = 2*stride, padding = (k-stride)//2 (InferenceBigVGAN.py:41-46).
 

@@ -158,6 +158,30 @@ typedef struct {
 } TtsWavenetDesc;
 int tts_wavenet_layer(const TtsWavenetDesc* d, tts_stream_t stream);
 
+/* Fused Conformer feed-forward module at kernel size 1 (Layers/EncoderLayer.py:84-90 and :128-136 with
+ * Layers/MultiLayeredConv1d.py:50-51 and Layers/LayerNorm.py:24-36), one launch for the 16-bit MFMA configurations:
+ *   y = [LayerNorm_post]( x + alpha * (W2 relu(W1 LayerNorm(x) + b1) + b2) )       rows are independent, y may be x
+ * x, y: fp32 [rows, 192]; ln_g / ln_b: the module's norm; post_g / post_b: the block's norm_final (NULL: none); eps for both.
+ * w: both weight matrices and b1 in the kernel's fragment order, 28 KB per 32 hidden channels:
+ *   chunk c = [12 fragments of W1 | 6 x 2 fragments of W2 | 4 fragments of b1], one 16-bit fragment = [64 lanes][8]:
+ *     W1 fragment ks   : lane (lk = lane / 32, r = lane % 32), element i  =  W1[32 c + r][16 ks + 8 lk + i]
+ *     W2 fragment j, ab: lane (lk, r), element i  =  W2[32 j + r][32 c + 16 ab + (i < 4 ? 4 lk + i : 8 + 4 lk + i - 4)]
+ *     b1 fragment q    : lane (lk, r), four fp32  =  b1[32 c + 8 q + 4 lk + 0 .. 3]   (the same for every r)
+ *   (W1 [hidden, 192] = w_1.weight[:, :, 0], W2 [192, hidden] = w_2.weight[:, :, 0]; the k order of a W2 fragment is the order in
+ *   which the first product's accumulator registers hold the hidden channels).
+ * hidden: multiple of 32; compute: TTS_COMPUTE_BF16 or TTS_COMPUTE_F16 (the format of w). */
+typedef struct {
+  const float* x;      int32_t ldx;
+  float* y;            int32_t ldy;
+  int32_t rows;        int32_t channels;   /* 192 */
+  const float* ln_g;   const float* ln_b;
+  const void* w;       const float* b2;    /* [192] */
+  const float* post_g; const float* post_b;
+  int32_t hidden;      int32_t compute;
+  float alpha;         float eps;
+} TtsFfnDesc;
+int tts_ffn_fused(const TtsFfnDesc* d, tts_stream_t stream);
+
 /* y[r,:] = LayerNorm(x[r,:]) * g + b over `c` channels, eps as given. Layers/LayerNorm.py:24-36 (eps 1e-12). */
 int tts_layernorm(const float* x, int32_t ldx, float* y, int32_t ldy, const float* gamma, const float* beta,
                   int32_t rows, int32_t c, float eps, tts_stream_t stream);
@@ -355,7 +379,7 @@ int tts_synthesize_batch(TtsHandle* h, const float* text, const float* utt_emb, 
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 10
+#define TTS_ABI_VERSION 11
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -224,6 +224,45 @@ class Emulator:
             _mat(d.hs_out, se, 384, d.ld_out)[sb:se, col0:col0 + n2] = out
         return 0
 
+    def tts_ffn_fused(self, dref, stream):
+        """Rounding points as in csrc/ffn.hip: LN(x) -> 16 bit; relu(W1 . + b1) -> 16 bit; fp32 accumulation, statistics and epilogue.
+        The weights arrive in the kernel's fragment order (include/toucan_tts.h) and are unpacked here."""
+        self._count("ffn_fused")
+        d = dref._obj
+        f16 = d.compute == capi.COMPUTE_F16
+        Cc, Hh = 192, d.hidden
+        n = Hh // 32
+        raw = _arr(d.w, n * 14 * 1024, np.uint16).reshape(n, 14 * 1024)
+        frag = _widen16(raw[:, :24 * 512].reshape(-1), f16).reshape(n, 24, 64, 8)
+        bias = raw[:, 24 * 512:].copy().view(np.float32).reshape(n, 4, 64, 4)
+        lane = np.arange(64)
+        lk, r = lane // 32, lane % 32
+        w1 = np.zeros((Hh, Cc), np.float64)
+        w2 = np.zeros((Cc, Hh), np.float64)
+        b1 = np.zeros(Hh, np.float32)
+        for c in range(n):
+            for ks in range(12):
+                for i in range(8):
+                    w1[32 * c + r, 16 * ks + 8 * lk + i] = frag[c, ks, lane, i]
+            for j in range(6):
+                for ab in range(2):
+                    for i in range(8):
+                        slot = 4 * lk + i if i < 4 else 8 + 4 * lk + i - 4
+                        w2[32 * j + r, 32 * c + 16 * ab + slot] = frag[c, 12 + 2 * j + ab, lane, i]
+            for q in range(4):
+                for i in range(4):
+                    b1[32 * c + 8 * q + 4 * lk + i] = bias[c, q, lane, i]
+        x = _mat(d.x, d.rows, Cc, d.ldx)[:d.rows].astype(np.float32)
+        ln = lambda v, g, b: (((v - v.mean(1, keepdims=True, dtype=np.float64)) / np.sqrt(v.astype(np.float64).var(1, keepdims=True) + d.eps))
+                              * _arr(g, Cc).astype(np.float64) + _arr(b, Cc).astype(np.float64)).astype(np.float32)
+        xn = _round16(ln(x, d.ln_g, d.ln_b), f16).astype(np.float64)
+        h = _round16(np.maximum((xn @ w1.T).astype(np.float32) + b1, 0.0), f16).astype(np.float64)
+        out = x + np.float32(d.alpha) * ((h @ w2.T).astype(np.float32) + _arr(d.b2, Cc).astype(np.float32))
+        if d.post_g:
+            out = ln(out, d.post_g, d.post_b)
+        _mat(d.y, d.rows, Cc, d.ldy)[:d.rows] = out
+        return 0
+
     def tts_snake_fir_table(self, filt, table):
         return self._reallib().tts_snake_fir_table(filt, table)  # host-only arithmetic: the real library's (the emulator ignores the table)
 

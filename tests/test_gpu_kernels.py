@@ -484,3 +484,43 @@ def test_fused_wavenet_layer(gpu, cpu, compute, cout2, lengths):
     two = run(gpu, lambda t: t.to("cuda:0").contiguous(), fused=False)
     torch.cuda.synchronize()
     close(g.cpu()[rows], two.cpu()[rows], TOL[compute])
+
+
+@pytest.mark.parametrize("compute", [capi.COMPUTE_BF16, capi.COMPUTE_F16])
+@pytest.mark.parametrize("rows,hidden,post", [(300, 1536, True), (128, 1536, False), (1, 64, True), (4096 + 37, 1536, True)])
+def test_fused_feed_forward(gpu, cpu, compute, rows, hidden, post):
+    """tts_ffn_fused (LayerNorm, w_1, ReLU, w_2, half-step residual, optional final LayerNorm in one launch; in place) against the
+    emulator - partial last workgroup, one row, a short hidden axis - and against the launches it replaces (same rounding
+    points, other summation order)."""
+    Cc = 192
+    w1 = rnd(hidden, Cc, 1, seed=1, scale=1.0 / np.sqrt(Cc)).numpy()
+    b1 = rnd(hidden, seed=2, scale=0.1).numpy()
+    w2 = rnd(Cc, hidden, 1, seed=3, scale=1.0 / np.sqrt(hidden)).numpy()
+    b2 = rnd(Cc, seed=4, scale=0.1).numpy()
+    fmt = PACK16[compute]
+
+    def run(ops, to, fused=True):
+        x = to(rnd(rows, Cc, seed=5, scale=2.0))
+        norm = (to(1.0 + rnd(Cc, seed=6, scale=0.1)), to(rnd(Cc, seed=7, scale=0.1)))
+        fin = (to(1.0 + rnd(Cc, seed=8, scale=0.1)), to(rnd(Cc, seed=9, scale=0.1))) if post else None
+        c1 = packing.pack_conv(w1, b1, ops.device, bf16=fmt)
+        c2 = packing.pack_conv(w2, b2, ops.device, bf16=fmt)
+        if fused:
+            pk = packing.pack_ffn(w1, b1, w2, ops.device, "f16" if fmt == "f16" else "bf16")
+            return ops.ffn_fused(x, x, norm, pk, c2.bias, rows, compute, post=fin)
+        rag = Ragged([rows], ops.device)
+        ln = to(torch.zeros(rows, Cc))
+        hid = to(torch.zeros(rows, hidden, dtype=DT16[compute]))
+        ops.layernorm(x, ln, *norm, rows, Cc)
+        ops.conv(c1, ln, hid, rag, act=capi.ACT_RELU, compute=compute)
+        ops.conv(c2, hid, x, rag, alpha=0.5, res=x, compute=compute)
+        if fin is not None:
+            ops.layernorm(x, x, *fin, rows, Cc)
+        return x
+
+    g, c = both(gpu, cpu, run)
+    close(g, c, TOL[compute])
+    if rows <= 300:
+        two = run(gpu, lambda t: t.to("cuda:0").contiguous(), fused=False)
+        torch.cuda.synchronize()
+        close(g.cpu(), two.cpu(), TOL[compute])
