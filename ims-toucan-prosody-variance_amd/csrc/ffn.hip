@@ -136,9 +136,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const TtsFfnDesc d) {
     const unsigned char* st = ring + (size_t)(c % FF_DEPTH) * FF_STAGE + lane * 16;
     bf16x8 a1[FF_KS], a2[FF_J][2], bbf[4];
 #pragma unroll
-    for (int k = 0; k < FF_KS; ++k) a1[k] = *reinterpret_cast<const bf16x8*>(st + k * 1024);
-#pragma unroll
     for (int k = 0; k < 4; ++k) bbf[k] = *reinterpret_cast<const bf16x8*>(st + (FF_KS + 2 * FF_J + k) * 1024);  // (b1 rides in the stage)
+    __builtin_amdgcn_sched_barrier(0);  // (b1, W1, W2 in the order of use: LDS reads return in order, every MFMA waits for its own operand only)
+#pragma unroll
+    for (int k = 0; k < FF_KS; ++k) {
+      a1[k] = *reinterpret_cast<const bf16x8*>(st + k * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int k = 0; k < 2 * FF_J; ++k) a2[k >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(st + (FF_KS + k) * 1024);
     __builtin_amdgcn_sched_barrier(0);
