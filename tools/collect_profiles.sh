@@ -13,7 +13,11 @@ python3 $R/bench.py --dtype fp16 --pitch-scale 1.3 --energy-scale 0.7 --no-cpu-b
 python3 $R/bench.py --dtype fp32 --no-cpu-baseline > $O/bench_fp32.json 2>/dev/null
 python3 $R/bench.py --vocoder hifigan --no-cpu-baseline > $O/bench_bf16_hifigan.json 2>/dev/null
 python3 $R/bench.py --sequencer python --no-cpu-baseline > $O/bench_bf16_python_sequencer.json 2>/dev/null
+python3 $R/bench.py --no-overlap --no-cpu-baseline > $O/bench_bf16_one_stream.json 2>/dev/null
 python3 $R/tools/latency_configs.py > $O/latency_configs.jsonl 2>/dev/null
+python3 $R/tools/stage_times.py > $O/stage_times_bf16.txt 2>/dev/null
+python3 $R/tools/conv_shapes.py > $O/conv_shapes_bf16.txt 2>/dev/null
+python3 $R/tools/microbench_ffn.py > $O/microbench_ffn_bf16.txt 2>/dev/null
 echo "[collect] kernel traces"; date
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bf16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/rocprof_bf16.log 2>&1
 cp /tmp/p_bf16/*kernel_stats.csv $O/bench_bf16_kernel_stats.csv
