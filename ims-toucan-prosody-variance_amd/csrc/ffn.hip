@@ -38,6 +38,20 @@ constexpr int FF_DEPTH = 5;
 // (LDS reads of the stages are ordinary loads.  Reading them through inline asm - to keep the compiler from ordering them
 // against the global -> LDS loads - does not work: under register pressure it copies an asm output to an accumulator register
 // right behind the asm statement, before the data has arrived.)
+// Timing diagnostics (tools/build_variant.sh NAME -DFF_DIAG_CLOCK): s_memtime stamps inside the chunk loop, summed per workgroup
+// into g_ff_clock (wave 0 of workgroup 0 only), read back by tts_ffn_diag_clock.  The shipped library carries no stamp.
+#ifdef FF_DIAG_CLOCK
+__device__ unsigned long long g_ff_clock[8];
+#define FF_STAMP(k_)                                                                    \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[k_])::"memory");   \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#else
+#define FF_STAMP(k_)
+#endif
+
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const TtsFfnDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -47,15 +61,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const TtsFfnDesc d) {
   const char* wsrc = reinterpret_cast<const char*>(d.w);
 
   // direct global -> LDS copy of stage s into ring[s % 3]: wave w moves units i * 256 + w * 64 + lane (1 KB per instruction)
-  auto issue = [&](int s) __attribute__((always_inline)) {
+  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {  // piece i (of 7) of this wavefront's share of stage s
     const char* src = wsrc + (size_t)s * FF_STAGE;
     unsigned char* dst = ring + (size_t)(s % FF_DEPTH) * FF_STAGE;
+    const int u0 = i * 256 + wave * 64;
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(u0 + lane) * 16),
+                                     (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 16), 16, 0, 0);
+  };
+  auto issue = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < FF_STAGE / 4096; ++i) {
-      const int u0 = i * 256 + wave * 64;
-      __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(u0 + lane) * 16),
-                                       (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < FF_STAGE / 4096; ++i) issue_piece(s, i);
   };
 #pragma unroll
   for (int s0 = 0; s0 < FF_DEPTH - 1; ++s0)
@@ -125,14 +140,21 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const TtsFfnDesc d) {
   // after the other - 1.3 us per chunk measured, 3 x the MFMA time.  Reading the next chunk's fragments under this chunk's MFMAs
   // needs a second register set, which pushed the operands into accumulator registers and cost more in copies than it hid.)
   wait_for(n_chunks - 1 < FF_DEPTH - 2 ? n_chunks - 1 : FF_DEPTH - 2);  // stage 0 (stages 0 .. FF_DEPTH - 2 were issued at the top)
+#ifdef FF_DIAG_CLOCK
+  unsigned long long stamp[6], psum[5] = {0, 0, 0, 0, 0};
+#endif
   for (int c = 0; c < n_chunks; ++c) {
+    FF_STAMP(0);
     if (c > 0) {
       // stage c is complete (chunks up to c + FF_DEPTH - 3 have been issued: FF_DEPTH - 3 stages may stay in flight), and every
       // wavefront is past its reads of chunk c - 1 ...
       const int behind = n_chunks - 1 - c;
       wait_for(behind < FF_DEPTH - 3 ? behind : FF_DEPTH - 3);
     }
-    if (c + FF_DEPTH - 2 < n_chunks && c > 0) issue(c + FF_DEPTH - 2);  // ... so that stage takes chunk c - 1 + FF_DEPTH - 1
+    FF_STAMP(1);
+    // ... so that stage takes chunk c + FF_DEPTH - 2; its seven loads are issued between the MFMAs of the second product below (a
+    // global -> LDS load costs 60 - 180 cycles of issue: 960 cycles per chunk measured when they sat in front of the LDS reads)
+    const bool refill = c + FF_DEPTH - 2 < n_chunks && c > 0;
     const unsigned char* st = ring + (size_t)(c % FF_DEPTH) * FF_STAGE + lane * 16;
     bf16x8 a1[FF_KS], a2[FF_J][2], bbf[4];
 #pragma unroll
@@ -146,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const TtsFfnDesc d) {
 #pragma unroll
     for (int k = 0; k < 2 * FF_J; ++k) a2[k >> 1][k & 1] = *reinterpret_cast<const bf16x8*>(st + (FF_KS + k) * 1024);
     __builtin_amdgcn_sched_barrier(0);
+    FF_STAMP(2);
     // h = W1[chunk] xb + b1 (the accumulator starts from the bias)
     f32x16 h;
 #pragma unroll
@@ -155,19 +178,44 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const TtsFfnDesc d) {
     }
 #pragma unroll
     for (int ks = 0; ks < FF_KS; ++ks) h = mfma16<F16>(a1[ks], xb[ks], h);
-    // ReLU, 16-bit: registers 4 rq + i of this lane are hidden channels 32 c + 8 rq + 4 lk + i = k slots of the second product
+    FF_STAMP(3);
+    // 16-bit, then ReLU on the packed pairs: registers 4 rq + i of this lane are hidden channels 32 c + 8 rq + 4 lk + i = k slots of
+    // the second product.  (max(v, 0) of a bf16 / fp16 value = signed 16-bit integer max of its bit pattern with 0: negative
+    // values have the sign bit set; -0 becomes +0.  One v_pk_max_i16 per pair instead of two v_max_f32 per pair.)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 p0 = {pack16<F16>(fmaxf(h[0], 0.f), fmaxf(h[1], 0.f)), pack16<F16>(fmaxf(h[2], 0.f), fmaxf(h[3], 0.f)),
-                      pack16<F16>(fmaxf(h[4], 0.f), fmaxf(h[5], 0.f)), pack16<F16>(fmaxf(h[6], 0.f), fmaxf(h[7], 0.f))};
-    const u32x4 p1 = {pack16<F16>(fmaxf(h[8], 0.f), fmaxf(h[9], 0.f)), pack16<F16>(fmaxf(h[10], 0.f), fmaxf(h[11], 0.f)),
-                      pack16<F16>(fmaxf(h[12], 0.f), fmaxf(h[13], 0.f)), pack16<F16>(fmaxf(h[14], 0.f), fmaxf(h[15], 0.f))};
+    typedef short i16x2 __attribute__((ext_vector_type(2)));
+    auto relu2 = [](unsigned int pr) __attribute__((always_inline)) {
+      const i16x2 z = {0, 0};
+      return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pr), z));
+    };
+    const u32x4 p0 = {relu2(pack16<F16>(h[0], h[1])), relu2(pack16<F16>(h[2], h[3])), relu2(pack16<F16>(h[4], h[5])), relu2(pack16<F16>(h[6], h[7]))};
+    const u32x4 p1 = {relu2(pack16<F16>(h[8], h[9])), relu2(pack16<F16>(h[10], h[11])), relu2(pack16<F16>(h[12], h[13])), relu2(pack16<F16>(h[14], h[15]))};
     const bf16x8 hb0 = __builtin_bit_cast(bf16x8, p0), hb1 = __builtin_bit_cast(bf16x8, p1);
+    FF_STAMP(4);
 #pragma unroll
-    for (int j = 0; j < FF_J; ++j) y[j] = mfma16<F16>(a2[j][0], hb0, y[j]);
+    for (int j = 0; j < FF_J; ++j) {
+      y[j] = mfma16<F16>(a2[j][0], hb0, y[j]);
+      if (refill) issue_piece(c + FF_DEPTH - 2, j);
+    }
 #pragma unroll
-    for (int j = 0; j < FF_J; ++j) y[j] = mfma16<F16>(a2[j][1], hb1, y[j]);
+    for (int j = 0; j < FF_J; ++j) {
+      y[j] = mfma16<F16>(a2[j][1], hb1, y[j]);
+      if (j == 0 && refill) issue_piece(c + FF_DEPTH - 2, FF_J);
+    }
     __builtin_amdgcn_sched_barrier(0);
+    FF_STAMP(5);
+#ifdef FF_DIAG_CLOCK
+#pragma unroll
+    for (int k = 0; k < 5; ++k) psum[k] += stamp[k + 1] - stamp[k];
+#endif
   }
+#ifdef FF_DIAG_CLOCK
+  if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) g_ff_clock[k] = psum[k];
+    g_ff_clock[5] = n_chunks;
+  }
+#endif
 
   // ---- epilogue: lane = frame, registers 4 rq + i of block j = channels 32 j + 8 rq + 4 lk + i
   float o[FF_J][4][4];
@@ -247,6 +295,12 @@ int ffn_fused(const TtsFfnDesc& d, hipStream_t st) {
 }
 
 }  // namespace tts
+
+#ifdef FF_DIAG_CLOCK
+extern "C" int tts_ffn_diag_clock(unsigned long long* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(tts::g_ff_clock), sizeof(tts::g_ff_clock)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int tts_ffn_fused(const TtsFfnDesc* d, tts_stream_t stream) {
   if (!d) {

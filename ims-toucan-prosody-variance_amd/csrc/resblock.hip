@@ -230,8 +230,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   float* cst_b2 = cst_b1 + C;                                               // [C]
   float* cst_snk = cst_b2 + C;                                              // [4][C]: e^a1 / 2 pi, 1 / (e^b1 + 1e-9), same for the second snake (FIR_LDS)
   uint4* cst_fir = reinterpret_cast<uint4*>(cst_snk + (MFIR && C < 128 ? 4 * C : 0));  // [256] (FIR_LDS && snake)
-  unsigned char* cst_dump = reinterpret_cast<unsigned char*>(cst_fir + (MFIR && C < 128 ? 256 : 0));  // [256 B] (L2PF: see l2_prefetch)
-  int* cst_ticket = reinterpret_cast<int*>(cst_dump + (MFIR ? 256 : 0));                             // [8] the next tile of this workgroup: index, -, -, -, its table entry
+  int* cst_ticket = reinterpret_cast<int*>(cst_fir + (MFIR && C < 128 ? 256 : 0));                   // [8] the next tile of this workgroup: index, -, -, -, its table entry
   unsigned int ticket_raw = 0;
   float f[12];  // (scalar loads: ahead of the first atomic)
 #pragma unroll
@@ -870,7 +869,7 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
   const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
   const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
-  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + (MFIR ? 256 : 0) + 32;
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + 32;
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised

@@ -45,7 +45,8 @@ def test_descriptor_layouts_match_the_header():
     """Field order of the ctypes structures == field order in the header (by name)."""
     text = open(HEADER, encoding="utf-8").read()
     for struct, cls in (("TtsConvDesc", capi.TtsConvDesc), ("TtsResblockDesc", capi.TtsResblockDesc), ("TtsTile", capi.TtsTile),
-                        ("TtsConfig", capi.TtsConfig), ("TtsWavenetDesc", capi.TtsWavenetDesc)):
+                        ("TtsConfig", capi.TtsConfig), ("TtsWavenetDesc", capi.TtsWavenetDesc),
+                        ("TtsFfnDesc", capi.TtsFfnDesc)):
         chunk = [c for c in text.split("typedef struct") if re.search(r"\}\s*" + struct + r"\s*;", c)][0]
         body = chunk[chunk.index("{") + 1:chunk.index("} " + struct)]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)

@@ -57,6 +57,16 @@ def main():
             torch.cuda.synchronize()
             out.append(1e3 * e0.elapsed_time(e1) / args.reps)
         print(f"{R:>7} {out[0]:9.1f} {4.0 * R * Cc * H / out[0] / 1e6:8.1f} {out[1]:11.1f}", flush=True)
+        diag = getattr(ops.lib, "tts_ffn_diag_clock", None)
+        if diag is not None:  # (diagnostic library built with -DFF_DIAG_CLOCK: shader cycles per chunk, workgroup 0 / wavefront 0)
+            import ctypes as C_
+            buf = (C_.c_ulonglong * 8)()
+            fused()
+            torch.cuda.synchronize()
+            diag(buf)
+            n = max(1, buf[5])
+            names = ("wait+barrier", "issue+reads", "first product", "relu/pack", "second product")
+            print("        cycles per chunk: " + "  ".join(f"{nm} {buf[i] / n:.0f}" for i, nm in enumerate(names)) + f"  | total {sum(buf[:5]) / n:.0f}", flush=True)
 
 
 if __name__ == "__main__":
