@@ -205,7 +205,9 @@ def main():
     overlap = use_native and not args.no_overlap
     s_ac = s_voc = None
     if overlap:
-        s_ac, s_voc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        # the acoustic stream has the higher priority: its short kernels take the CUs a vocoder launch frees in its tail before
+        # the next vocoder launch's persistent workgroups do (42.0 vs 42.25 ms measured; TOUCAN_BENCH_AC_PRIORITY=0 for the A/B run)
+        s_ac, s_voc = torch.cuda.Stream(dev, priority=int(os.environ.get("TOUCAN_BENCH_AC_PRIORITY", "-1"))), torch.cuda.Stream(dev)
 
     def step_overlapped(record=False):
         """Two streams: the acoustic model of this step is enqueued on s_ac, its vocoder on s_voc behind an event; the next

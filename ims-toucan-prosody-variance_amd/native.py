@@ -289,7 +289,7 @@ class NativePipeline:
         with torch.cuda.device(self.device):
             caller = torch.cuda.current_stream(self.device)
             if self._streams is None:
-                self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+                self._streams = (torch.cuda.Stream(self.device, priority=-1), torch.cuda.Stream(self.device))  # (acoustic: high priority)
             s_ac, s_voc = self._streams
             s_ac.wait_stream(caller)
             s_voc.wait_stream(caller)
