@@ -365,6 +365,10 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 
   load_slab(0);
   store_slab(0);
+  // Two slab steps in all (C = 32: a whole conv per slab) = both convs' weights fit the ring: after the first tile of this
+  // workgroup they are simply there - no loads, no staging stores, no waits for them in any later tile.
+  const bool weights_resident = total_steps == 2;
+  bool first_tile = true;
 
   f32x16 acc[TN];
 
@@ -557,7 +561,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       rb_barrier();
-      load_slab(step + 1);  // step + 1 < total_steps always holds here (conv2 follows)
+      const bool restage = !weights_resident || first_tile;
+      if (restage) load_slab(step + 1);  // step + 1 < total_steps always holds here (conv2 follows)
       const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
       for (int tt = 0; tt < nt; ++tt) {
         const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
           }
         }
       }
-      store_slab((step + 1) & 1);
+      if (restage) store_slab((step + 1) & 1);
     }
   }
 
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   auto conv2_step = [&](auto first, int ch, int tap0) __attribute__((always_inline)) {
     rb_barrier();
     // (after the last step the ring's buffer 0 is free again: the next tile's first slab goes there)
-    const bool more = step + 1 < total_steps || has_next;
+    const bool more = (step + 1 < total_steps || has_next) && !weights_resident;  // (resident: conv2's slab came with the first tile's conv1)
     if (more) load_slab(step + 1 < total_steps ? step + 1 : 0);
     if constexpr (decltype(first)::value) {
       if constexpr (PREFETCH_RES) {
@@ -831,6 +836,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #endif
   }
   if (!has_next) break;
+  first_tile = false;
   tile = tile_next;
   cur_tile = next_tile;
   }  // tiles of this workgroup
