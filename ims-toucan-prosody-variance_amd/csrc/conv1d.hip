@@ -331,6 +331,50 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         for (int i = 0; i < 8; ++i)
           if (wr0 + i < win_rows) xs[(wr0 + i) * XP + chl] = Elem<BF16, F16>::cvt((live && t0 + i >= 0 && t0 + i < T) ? o[i] : 0.0f);
       }
+    } else if (BF16 && BM != 64 && vec_ok && x_bf16 && (d.cin & 7) == 0 && (d.ldx & 7) == 0 && (reinterpret_cast<uintptr_t>(d.x) & 15) == 0) {
+      // 16-bit input of a 16-bit kernel (its own format): 8 channels = 16 bytes per load, and up to six loads per thread in flight -
+      // the whole window of a 128-row tile (<= 178 rows x 8 units) in ONE memory round trip instead of three; without a
+      // pre-activation the unit goes to LDS as it is
+      // (large tiles only: compiled into the 64-row small-batch form too, it made several of its shapes 30 - 60 % slower although
+      // they never take this branch)
+      if constexpr (BF16 && BM != 64) {
+        constexpr int PER8 = 6;
+        const int q8 = kchunk >> 3;
+        const int total = win_rows * q8;
+        for (int base = tid; base < total; base += 256 * PER8) {
+          uint4 raw[PER8];
+#pragma unroll
+          for (int p = 0; p < PER8; ++p) {
+            int e = base + p * 256;
+            e = e < total ? e : total - 1;
+            const int wr = e / q8, c8 = (e % q8) * 8;
+            const int gr = row_first + wr;
+            const int grc = gr < tile.seq_begin ? tile.seq_begin : (gr >= tile.seq_end ? tile.seq_end - 1 : gr);
+            const int cc = (c0 + c8) < d.cin ? (c0 + c8) : d.cin - 8;
+            raw[p] = *reinterpret_cast<const uint4*>(xh + (size_t)grc * d.ldx + cc);
+          }
+#pragma unroll
+          for (int p = 0; p < PER8; ++p) {
+            const int e = base + p * 256;
+            if (e >= total) continue;
+            const int wr = e / q8, c8 = (e % q8) * 8;
+            const int gr = row_first + wr;
+            const bool ok = gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c8) < d.cin;
+            uint4 o = raw[p];
+            if (d.pre_act != TTS_PRE_NONE) {
+              const unsigned int w4[4] = {o.x, o.y, o.z, o.w};
+              unsigned int r4[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                r4[q] = pack16<F16>(pre_activation(from16<F16>(w4[q] & 0xFFFF), d.pre_act, d.pre_slope),
+                                    pre_activation(from16<F16>(w4[q] >> 16), d.pre_act, d.pre_slope));
+              o = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+            }
+            if (!ok) o = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(xs + wr * XP + c8) = o;
+          }
+        }
+      }
     } else if (vec_ok) {
       // PER independent 16-byte loads per thread are issued back to back (clamped addresses, no branches) before any of
       // them is consumed, so one trip pays the memory latency once instead of PER times
