@@ -196,6 +196,8 @@ def main():
     scales = dict(pitch_variance_scale=args.pitch_scale, energy_variance_scale=args.energy_scale)
     # 1-D concatenation form of the gather output (accepted by every backend)
     gathered = torch.empty(world * B * T * 384, device="cpu" if rehearsal else dev) if world > 1 else None
+    gathered2 = [gathered, torch.empty_like(gathered)] if world > 1 else None  # (two-stream form: the exchange of step k runs beside step k+1)
+    gather_no = [0]
 
     packed = z_sq = None
     if use_native:  # the stage API's input format (packed along the phoneme axis): resident in HBM before the timed region
@@ -203,8 +205,9 @@ def main():
         z_sq = pipe.squeeze_noise(zs, [T] * B)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     overlap = use_native and not args.no_overlap
-    s_ac = s_voc = None
+    s_ac = s_voc = s_comm = None
     if overlap:
+        s_comm = torch.cuda.Stream(dev) if world > 1 else None
         # the acoustic stream has the higher priority: its short kernels take the CUs a vocoder launch frees in its tail before
         # the next vocoder launch's persistent workgroups do (42.0 vs 42.25 ms measured; TOUCAN_BENCH_AC_PRIORITY=0 for the A/B run)
         s_ac, s_voc = torch.cuda.Stream(dev, priority=int(os.environ.get("TOUCAN_BENCH_AC_PRIORITY", "-1"))), torch.cuda.Stream(dev)
@@ -229,8 +232,20 @@ def main():
             if record:
                 ev[2].record(s_voc)
             if world > 1:
+                # the exchange step on its own stream: the vocoder of step k+1 does not wait for the waveforms of step k to cross
+                # xGMI (31.5 MB per rank and step); all of it is inside the timed region (the final device synchronise)
                 block = wav[: B * T * 384].contiguous()
-                dist.all_gather_into_tensor(gathered, block.cpu() if rehearsal else block)
+                voc_done = torch.cuda.Event()
+                voc_done.record(s_voc)
+                dst = gathered2[gather_no[0] & 1]
+                gather_no[0] += 1
+                if rehearsal:
+                    dist.all_gather_into_tensor(dst, block.cpu())
+                else:
+                    with torch.cuda.stream(s_comm):
+                        s_comm.wait_event(voc_done)
+                        block.record_stream(s_comm)
+                        dist.all_gather_into_tensor(dst, block)
         return out, wav
 
     def step(record=False, tx=texts, em=embs, zz=zs, resident=True):
