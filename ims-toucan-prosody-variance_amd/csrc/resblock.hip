@@ -19,6 +19,9 @@
 // bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <type_traits>
 #include <cstring>
 
@@ -885,11 +888,27 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   }
   // persistent grid: as many workgroups as the device keeps resident at this LDS size (rounded up to whole rounds of the 8 XCDs),
   // never more than tiles
+  // (queried once per instantiation, device and LDS size: the answers do not change, the runtime calls cost microseconds each)
   int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), RB_THREADS, lds) != hipSuccess || cus < 1 || per_cu < 1) {
-    set_error("resblock_step: occupancy query failed");
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("resblock_step: hipGetDevice failed");
     return TTS_E_LAUNCH;
+  }
+  {
+    static std::mutex cache_lock;
+    static std::map<std::pair<int, size_t>, std::pair<int, int>> cache;  // (device, lds) -> (CUs, workgroups per CU)
+    std::lock_guard<std::mutex> guard(cache_lock);
+    auto it = cache.find({dev, lds});
+    if (it == cache.end()) {
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k), RB_THREADS, lds) != hipSuccess || cus < 1 || per_cu < 1) {
+        set_error("resblock_step: occupancy query failed");
+        return TTS_E_LAUNCH;
+      }
+      it = cache.emplace(std::make_pair(dev, lds), std::make_pair(cus, per_cu)).first;
+    }
+    cus = it->second.first;
+    per_cu = it->second.second;
   }
   static const int fixed_per_cu = std::getenv("TOUCAN_RB_WG_PER_CU") ? std::atoi(std::getenv("TOUCAN_RB_WG_PER_CU")) : 0;  // (A/B runs)
   if (fixed_per_cu > 0) per_cu = fixed_per_cu;

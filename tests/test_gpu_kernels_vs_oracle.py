@@ -77,3 +77,41 @@ def test_fused_feed_forward_matches_the_oracles_ffn(compute, rows, post):
                         post=(g2.to(DEV), b2.to(DEV)) if post else None)
     torch.cuda.synchronize()
     close(got, want, TOL[compute])
+
+
+@pytest.mark.parametrize("compute", [capi.COMPUTE_F16, capi.COMPUTE_BF16])
+def test_fused_wavenet_layers_match_the_oracles_wavenet(compute):
+    """The four layers of one PostFlow WaveNet (wavenet.py:89-122 as the oracle states it: in_layer + conditioning, tanh . sigmoid,
+    res_skip layer, state / skip update) through four tts_wavenet_layer launches on a ragged batch; the hidden state ping-pongs
+    between two buffers as in the pipeline."""
+    ops = engine.Ops(torch.device(DEV))
+    H = 192
+    lengths = [300, 65, 7]
+    sd = {}
+    for i in range(4):
+        sd[f"in_layers.{i}.weight"] = rnd(2 * H, H, 5, seed=10 + i, scale=1.0 / np.sqrt(5 * H))
+        sd[f"in_layers.{i}.bias"] = rnd(2 * H, seed=20 + i, scale=0.1)
+        co = 2 * H if i < 3 else H
+        sd[f"res_skip_layers.{i}.weight"] = rnd(co, H, 1, seed=30 + i, scale=1.0 / np.sqrt(H))
+        sd[f"res_skip_layers.{i}.bias"] = rnd(co, seed=40 + i, scale=0.1)
+    sd["cond_layer.weight"] = rnd(8 * H, 2 * H, 1, seed=50, scale=1.0 / np.sqrt(2 * H))
+    sd["cond_layer.bias"] = rnd(8 * H, seed=51, scale=0.1)
+    rag = Ragged(lengths, ops.device, align=2)
+    R = rag.total_rows
+    x = rnd(R, H, seed=1)
+    g = rnd(R, 2 * H, seed=2)
+    cond = F.conv1d(g.t().unsqueeze(0), sd["cond_layer.weight"], sd["cond_layer.bias"])[0].t().contiguous()  # [R, 1536] (rows are independent)
+    hs = [torch.zeros(R, 2 * H), torch.zeros(R, 2 * H)]
+    hs[0][:, :H] = x
+    hs = [h.to(DEV).contiguous() for h in hs]
+    cond_d = cond.to(DEV).contiguous()
+    for i in range(4):
+        inl = packing.pack_conv(sd[f"in_layers.{i}.weight"].numpy(), sd[f"in_layers.{i}.bias"].numpy(), ops.device, mode=capi.MODE_GATED, bf16=FMT[compute])
+        rs = packing.pack_conv(sd[f"res_skip_layers.{i}.weight"].numpy(), sd[f"res_skip_layers.{i}.bias"].numpy(), ops.device, bf16=FMT[compute])
+        src, dst = hs[i & 1], hs[(i + 1) & 1]  # (a layer writes [h + res | skip + skip'] of its input buffer into the other one)
+        ops.wavenet_layer(inl, rs, src, dst, cond_d[:, i * 2 * H:(i + 1) * 2 * H], rag)
+    torch.cuda.synchronize()
+    got = hs[0][:, H:]  # after four layers the result sits in buffer 0's skip half
+    for b0, n in zip(rag.begins, rag.lengths):
+        want = oracle.wavenet(x[b0:b0 + n].t().contiguous(), g[b0:b0 + n].t().contiguous(), sd, "").t()
+        close(got[b0:b0 + n], want, TOL[compute])
