@@ -198,6 +198,7 @@ def main():
     gathered = torch.empty(world * B * T * 384, device="cpu" if rehearsal else dev) if world > 1 else None
     gathered2 = [gathered, torch.empty_like(gathered)] if world > 1 else None  # (two-stream form: the exchange of step k runs beside step k+1)
     gather_no = [0]
+    comm_stream_ok = [True]
 
     packed = z_sq = None
     if use_native:  # the stage API's input format (packed along the phoneme axis): resident in HBM before the timed region
@@ -241,11 +242,18 @@ def main():
                 gather_no[0] += 1
                 if rehearsal:
                     dist.all_gather_into_tensor(dst, block.cpu())
-                else:
-                    with torch.cuda.stream(s_comm):
-                        s_comm.wait_event(voc_done)
-                        block.record_stream(s_comm)
+                elif comm_stream_ok[0]:
+                    try:
+                        with torch.cuda.stream(s_comm):
+                            s_comm.wait_event(voc_done)
+                            block.record_stream(s_comm)
+                            dist.all_gather_into_tensor(dst, block)
+                    except Exception as e:  # (never seen; the plain form below is the one round 1 measured)
+                        log(f"exchange on its own stream failed ({e!r}): falling back to the vocoder stream")
+                        comm_stream_ok[0] = False
                         dist.all_gather_into_tensor(dst, block)
+                else:
+                    dist.all_gather_into_tensor(dst, block)
         return out, wav
 
     def step(record=False, tx=texts, em=embs, zz=zs, resident=True):
