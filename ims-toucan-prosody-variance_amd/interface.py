@@ -174,8 +174,6 @@ class ToucanTTSInterface(torch.nn.Module):
                 energy=None,
                 input_is_phones=False,
                 return_plot_as_filepath=False):
-        if view or return_plot_as_filepath:
-            raise NotImplementedError("plotting (matplotlib/librosa) is outside the hot path")
         with torch.inference_mode():
             phones = self.text2phone.string_to_tensor(text, input_phonemes=input_is_phones)
             wavs = self._synthesize([phones], [self.default_utterance_embedding], [self._lang()],
@@ -185,6 +183,17 @@ class ToucanTTSInterface(torch.nn.Module):
                                     duration_scaling_factor=duration_scaling_factor, pitch_variance_scale=pitch_variance_scale,
                                     energy_variance_scale=energy_variance_scale,
                                     pause_duration_scaling_factor=pause_duration_scaling_factor)
+        if view or return_plot_as_filepath:  # ToucanTTSInterface.py:171-226 (matplotlib only: plotting.py)
+            from . import plotting
+            if input_is_phones:
+                labels = text.replace(" ", "|")
+            else:
+                labels = self.text2phone.get_phone_string(text, for_plot_labels=True)
+            fig = plotting.draw(wavs[0].cpu().numpy(), self.last_mel[0].cpu().numpy(), self.last_durations[0].cpu().numpy(),
+                                self.last_pitch[0].cpu().numpy(), labels, text)
+            if return_plot_as_filepath:
+                return wavs[0], plotting.show_or_save(fig, "tmp.png")
+            plotting.show_or_save(fig)
         return wavs[0]
 
     def _synthesize_packed(self, phones, embs, langs, z_noise=None, **kw):
@@ -194,10 +203,12 @@ class ToucanTTSInterface(torch.nn.Module):
         if self.pipe is not None:
             out = self.pipe.forward(phones, emb, lang_ids, z_noise=z_noise, **kw)
             self.last_durations, self.last_pitch, self.last_energy = out["durations"], out["pitch"], out["energy"]
+            self.last_mel = out["mel"]
             return out["wav"], out["wav_spans"]
         out = self.phone2mel.forward(phones, emb, lang_ids, z_noise=z_noise, **kw)
         wav, rag = self.mel2wav.forward(out["mel_packed"], out["rag_mel"])
         self.last_durations, self.last_pitch, self.last_energy = out["durations"], out["pitch"], out["energy"]
+        self.last_mel = out["mel"]
         return wav, list(zip(rag.begins, rag.lengths))
 
     def _synthesize(self, phones, embs, langs, z_noise=None, **kw):

@@ -330,6 +330,11 @@ def test_drop_in_interface_on_the_gpu(tmp_path, monkeypatch):
             assert f.getframerate() == 24000 and f.getnframes() > 3 * 10600
         both = tts.synthesize_batch(["~həlˈoʊ~#", "~wˈɜːld tˈu~#"])
         assert len(both) == 2 and all(w.is_cuda for w in both)
+    import matplotlib
+    matplotlib.use("Agg")
+    monkeypatch.chdir(tmp_path)
+    wav2, png = tts("~həlˈoʊ wˈɜːld~#", input_is_phones=True, return_plot_as_filepath=True)  # ToucanTTSInterface.py:171-226
+    assert png == "tmp.png" and (tmp_path / "tmp.png").stat().st_size > 10_000 and wav2.is_cuda
 
 
 @pytest.mark.parametrize("kind", ["hifigan", "bigvgan"])

@@ -50,14 +50,24 @@ def test_forward_returns_24khz_wave_with_384_samples_per_frame(tts):
     assert float(wav.abs().max()) <= 1.0
 
 
+def test_forward_draws_the_reference_figure(monkeypatch, tmp_path, tts):
+    """return_plot_as_filepath=True: (wave, "tmp.png") like ToucanTTSInterface.py:222-226, the file written to the working directory."""
+    import matplotlib
+    matplotlib.use("Agg")
+    monkeypatch.chdir(tmp_path)
+    plain = tts(PHONES_B, input_is_phones=True)
+    wav, path = tts(PHONES_B, input_is_phones=True, return_plot_as_filepath=True)
+    assert path == "tmp.png" and (tmp_path / "tmp.png").stat().st_size > 10_000
+    assert wav.shape == plain.shape and torch.isfinite(wav).all()  # (every call draws its own PostFlow noise, like the reference)
+    assert tts(PHONES_B, input_is_phones=True, view=True).shape == plain.shape  # (plt.show() is a no-op on the Agg backend)
+
+
 def test_missing_checkpoint_and_unsupported_paths_fail_loudly(monkeypatch, models_dir, tts):
     monkeypatch.setattr(interface, "MODELS_DIR", models_dir)
     with pytest.raises(FileNotFoundError):
         interface.ToucanTTSInterface(device="cpu", tts_model_path="DoesNotExist")
     with pytest.raises(RuntimeError, match="espeak"):
         tts("plain text needs a phonemizer")
-    with pytest.raises(NotImplementedError):
-        tts(PHONES_B, input_is_phones=True, view=True)
     tts.set_language("de")
     assert int(tts.lang_id[0]) == 1
     tts.set_utterance_embedding(embedding=torch.ones(1, 64))
