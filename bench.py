@@ -43,9 +43,9 @@ def parse_args():
     ap.add_argument("--phones", type=int, default=128)
     ap.add_argument("--frames-per-phone", type=int, default=5)
     ap.add_argument("--vocoder", default="bigvgan", choices=["bigvgan", "hifigan"])
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16"],
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16", "mixed"],
                     help="bf16 = BASELINE.json configs[2] (bf16 MFMA GEMMs, fp32 statistics); fp16 = configs[4]'s fp16 MFMA path; "
-                         "fp32 = exact-parity configuration")
+                         "fp32 = exact-parity configuration; mixed = acoustic model in fp32 (exact mel parity) + fp16 vocoder")
     ap.add_argument("--pitch-scale", type=float, default=1.0, help="pitch_variance_scale (configs[4]: 1.3)")
     ap.add_argument("--energy-scale", type=float, default=1.0, help="energy_variance_scale (configs[4]: 0.7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -172,15 +172,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    precision = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype]
+    precision = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "mixed": "f32"}[args.dtype]
+    voc_precision = "f16" if args.dtype == "mixed" else precision  # mixed: exact-parity acoustic model (fp32) + fp16 vocoder
     log(f"building engines (fixture weights, {precision})")
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
     use_native = args.sequencer == "native" and not args.graphs and not args.fuse_snake
     if use_native:
-        pipe = native.NativePipeline(fw.acoustic_state_dict(), voc_sd, args.vocoder, dev, precision=precision)
+        pipe = native.NativePipeline(fw.acoustic_state_dict(), voc_sd, args.vocoder, dev, precision=precision, vocoder_precision=voc_precision)
     else:
         ac = engine.AcousticEngine(fw.acoustic_state_dict(), dev, precision=precision, use_graphs=args.graphs)
-        voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, precision=precision, fuse_snake=args.fuse_snake, use_graphs=args.graphs)
+        voc = engine.VocoderEngine(voc_sd, args.vocoder, dev, precision=voc_precision, fuse_snake=args.fuse_snake, use_graphs=args.graphs)
 
     B, L, T = args.batch, args.phones, args.phones * args.frames_per_phone
     log(f"synthetic inputs: {B} x {L} phonemes -> {T} frames per utterance")
@@ -404,7 +405,8 @@ def main():
                     "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                     "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / args.steps,
                     "flops_per_launch": dom["flops_per_launch"], "share_of_step": dom["total_ms"] / (1e3 * elapsed)}
-        cfg_name = "configs[2]" if args.dtype == "bf16" else ("configs[4] (per-GPU shard)" if args.dtype == "fp16" else "configs[2] shape in fp32")
+        cfg_name = {"bf16": "configs[2]", "fp16": "configs[4] (per-GPU shard)", "fp32": "configs[2] shape in fp32",
+                    "mixed": "configs[2] shape, acoustic model in fp32 (exact mel parity) + fp16 vocoder"}[args.dtype]
         line = {
             "metric": "mel-frames/sec + vocoder RTF @24kHz, batch=32, 1/2/4/8 MI355X",
             "value": world * frames_out * args.steps / elapsed,
@@ -412,13 +414,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "mixed": "f32 (acoustic) + f16 (vocoder)"}[args.dtype], "data": "synthetic",
             "config": {"workload": f"{cfg_name}: batch={B}/GPU x {L} phonemes -> {T} frames, acoustic (PostFlow on) + {args.vocoder}, "
                                    f"gold durations {args.frames_per_phone}/phoneme (duration predictor bypassed; pitch / energy predicted), "
                                    f"pitch scale {args.pitch_scale}, energy scale {args.energy_scale}, fixture weights",
                        "global_batch": world * B, "phones": L, "frames_per_utt": frames_out // B, "vocoder": args.vocoder,
-                       "acoustic_dtype": f"{args.dtype} MFMA / f32 activations" if args.dtype != "fp32" else "f32",
-                       "vocoder_dtype": args.dtype if args.dtype != "fp32" else "f32", "parallelism": f"dp{world}",
+                       "acoustic_dtype": f"{args.dtype} MFMA / f32 activations" if args.dtype in ("bf16", "fp16") else "f32",
+                       "vocoder_dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "fp16", "mixed": "fp16"}[args.dtype], "parallelism": f"dp{world}",
                        "hip_graphs": bool(args.graphs),
                        "sequencer": "native stage API (csrc/pipeline.hip)" if use_native else "python (engine.py)",
                        "streams": "2 HIP streams: acoustic model of step k+1 beside the vocoder of step k" if overlap else "1 HIP stream"},

@@ -106,8 +106,11 @@ class ToucanTTSInterface(torch.nn.Module):
         sd = _to_numpy_sd(checkpoint["model"])
         # variant detection: the reference retries load_state_dict (:55-63); the schema tells us directly
         self.use_lang_id = "encoder.language_embedding.weight" in sd
-        # precision of the MFMA GEMMs: fp32 (exact-parity default), or TOUCAN_PRECISION=bf16 / f16 (BASELINE.json configs[2] / [4])
+        # precision of the MFMA GEMMs: fp32 (exact-parity default), TOUCAN_PRECISION=bf16 / f16 (BASELINE.json configs[2] / [4]), or
+        # TOUCAN_PRECISION=mixed: acoustic model in fp32 (the mel keeps exact parity), vocoder on the fp16 matrix cores
         precision = os.environ.get("TOUCAN_PRECISION", "f32")
+        voc_precision = "f16" if precision == "mixed" else precision
+        precision = "f32" if precision == "mixed" else precision
         voc = _load_checkpoint(vocoder_model_path)
         voc_sd, kind = _to_numpy_sd(voc["generator"]), "hifigan" if faster_vocoder else "bigvgan"
         # On a GPU the whole pass runs through the stage API (native.NativePipeline -> csrc/pipeline.hip: the kernels are sequenced in
@@ -117,11 +120,11 @@ class ToucanTTSInterface(torch.nn.Module):
         self.pipe = None
         if torch.device(device).type == "cuda" and isinstance(capi.lib(), ctypes.CDLL) and not os.environ.get("TOUCAN_PY_SEQUENCER"):
             from . import native
-            self.pipe = native.NativePipeline(sd, voc_sd, kind, device, precision=precision)
+            self.pipe = native.NativePipeline(sd, voc_sd, kind, device, precision=precision, vocoder_precision=voc_precision)
             self.phone2mel = self.mel2wav = self.pipe  # (the reference's attribute names; both stages live in the one handle)
         else:
             self.phone2mel = engine.AcousticEngine(sd, device, precision=precision)
-            self.mel2wav = engine.VocoderEngine(voc_sd, kind, device, precision=precision)
+            self.mel2wav = engine.VocoderEngine(voc_sd, kind, device, precision=voc_precision)
 
         self.embedding_model_path = embedding_model_path  # GST network: loaded on the first set_utterance_embedding(path)
         self._style = None

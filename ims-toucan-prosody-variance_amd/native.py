@@ -21,7 +21,10 @@ _NORMS = ("norm_ff_macaron", "norm_mha", "norm_conv", "norm_ff", "norm_final")
 class NativePipeline:
     """One handle per (process, device): acoustic model + (optionally) one vocoder."""
 
-    def __init__(self, acoustic_sd, vocoder_sd=None, vocoder_kind=None, device="cuda", precision="f32", pmax=1024):
+    def __init__(self, acoustic_sd, vocoder_sd=None, vocoder_kind=None, device="cuda", precision="f32", pmax=1024, vocoder_precision=None):
+        """precision: of the acoustic model ("f32" | "bf16" | "f16").  vocoder_precision (default: the same): a different one gives
+        the vocoder its own handle - e.g. precision="f32", vocoder_precision="f16": the mel keeps the exact-parity arithmetic
+        (mel L1 <= 1e-5 against the reference) and the vocoder, the bulk of the work, runs on the 16-bit matrix cores."""
         self.lib = capi.lib()
         if not isinstance(self.lib, C.CDLL):
             raise capi.ToucanHipError("the stage API needs the real libtoucan_hip.so (the test emulator only restates kernels)")
@@ -31,6 +34,8 @@ class NativePipeline:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.precision, _, compute, self.dt16 = engine.precision_of(False, precision)
+        self.vocoder_precision, _, compute_v, _ = engine.precision_of(False, precision if vocoder_precision is None else vocoder_precision)
+        split = vocoder_sd is not None and self.vocoder_precision != self.precision
         ac = engine.AcousticEngine(acoustic_sd, "cpu", precision=self.precision, pack_only=True)
         self.multilingual, self.multispeaker = ac.multilingual, ac.multispeaker
         voc = None
@@ -38,26 +43,38 @@ class NativePipeline:
         self._streams = None  # (acoustic, vocoder) stream pair of forward_pipelined, made on first use
         if vocoder_sd is not None:
             assert vocoder_kind in ("hifigan", "bigvgan")
-            voc = engine.VocoderEngine(vocoder_sd, vocoder_kind, "cpu", precision=self.precision, pack_only=True)
-        cfg = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), {None: 0, "hifigan": 1, "bigvgan": 2}[vocoder_kind], compute, 0,
-                             float(voc.post_b) if voc is not None else 0.0)
+            voc = engine.VocoderEngine(vocoder_sd, vocoder_kind, "cpu", precision=self.vocoder_precision, pack_only=True)
+        kind_code = {None: 0, "hifigan": 1, "bigvgan": 2}[vocoder_kind]
+        post_b = float(voc.post_b) if voc is not None else 0.0
+        cfg = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), 0 if split else kind_code, compute, 0, post_b)
         self.h = C.c_void_p()
+        self.h_voc = self.h  # the handle the vocoder entries are called on (its own when the precisions differ)
         with torch.cuda.device(self.device):
             capi.check(self.lib.tts_create(C.byref(cfg), C.byref(self.h)), "tts_create")
+            self._target = self.h  # the handle _load() uploads to
             self._upload_acoustic(ac)
+            if split:
+                self.h_voc = C.c_void_p()
+                cfg_v = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), kind_code, compute_v, 0, post_b)
+                capi.check(self.lib.tts_create(C.byref(cfg_v), C.byref(self.h_voc)), "tts_create (vocoder)")
+            else:
+                self.h_voc = self.h
             if voc is not None:
+                self._target = self.h_voc
                 self._upload_vocoder(voc)
+                self._target = self.h
             self._pmax = 0
             self._ensure_pe(pmax)
 
     def __del__(self):
-        h = getattr(self, "h", None)
-        if h is not None and h.value:
-            try:
-                self.lib.tts_destroy(h)
-            except Exception:
-                pass
-            self.h = None
+        h, hv = getattr(self, "h", None), getattr(self, "h_voc", None)
+        for handle in ([hv] if (hv is not None and hv is not h) else []) + [h]:
+            if handle is not None and handle.value:
+                try:
+                    self.lib.tts_destroy(handle)
+                except Exception:
+                    pass
+        self.h = self.h_voc = None
 
     # ---- weight upload ------------------------------------------------------------------------------------------------
     def _load(self, name, t):
@@ -70,7 +87,7 @@ class NativePipeline:
             code = _DT[t.dtype]
             raw = t.view(torch.int16).numpy() if t.dtype in (torch.bfloat16, torch.float16) else t.numpy()
         shape = (C.c_int64 * max(1, t.dim()))(*([int(s) for s in t.shape] or [1]))
-        capi.check(self.lib.tts_load_weights(self.h, name.encode(), raw.ctypes.data_as(C.c_void_p), shape, max(1, t.dim()), code),
+        capi.check(self.lib.tts_load_weights(self._target, name.encode(), raw.ctypes.data_as(C.c_void_p), shape, max(1, t.dim()), code),
                    f"tts_load_weights({name})")
 
     def _conv(self, name, cw):
@@ -166,21 +183,26 @@ class NativePipeline:
 
     def profile(self, enable, select=None):
         """Roofline leg: HIP events around the launches of one matrix-core kernel class (None: all) inside the stage entries."""
-        capi.check(self.lib.tts_profile(self.h, int(enable), None if select is None else select.encode()), "tts_profile")  # 2: per-shape conv classes
+        for handle in self._handles():
+            capi.check(self.lib.tts_profile(handle, int(enable), None if select is None else select.encode()), "tts_profile")  # 2: per-shape conv classes
+
+    def _handles(self):
+        return [self.h] if self.h_voc is self.h else [self.h, self.h_voc]
 
     def profile_summary(self):
         """class -> dict(launches, total_ms, avg_us, flops_per_launch, bytes_per_launch, elems_per_launch, tflops) (waits for the events)."""
         out = {}
         name = C.create_string_buffer(128)
         ms, fl, by, el = C.c_double(), C.c_double(), C.c_double(), C.c_double()
-        for i in range(int(self.lib.tts_profile_count(self.h))):
-            capi.check(self.lib.tts_profile_read(self.h, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by), C.byref(el)), "tts_profile_read")
-            s = out.setdefault(name.value.decode(), dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, elems=0.0))
-            s["launches"] += 1
-            s["total_ms"] += ms.value
-            s["flops"] += fl.value
-            s["bytes"] += by.value
-            s["elems"] += el.value
+        for handle in self._handles():
+            for i in range(int(self.lib.tts_profile_count(handle))):
+                capi.check(self.lib.tts_profile_read(handle, i, name, 128, C.byref(ms), C.byref(fl), C.byref(by), C.byref(el)), "tts_profile_read")
+                s = out.setdefault(name.value.decode(), dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, elems=0.0))
+                s["launches"] += 1
+                s["total_ms"] += ms.value
+                s["flops"] += fl.value
+                s["bytes"] += by.value
+                s["elems"] += el.value
         for s in out.values():
             n = s["launches"]
             s["avg_us"] = 1e3 * s["total_ms"] / n
@@ -189,7 +211,7 @@ class NativePipeline:
         return out
 
     def workspace_bytes(self, B, Lmax, Tmax):
-        return int(self.lib.tts_workspace_bytes(self.h, B, Lmax, Tmax))
+        return sum(int(self.lib.tts_workspace_bytes(handle, B, Lmax, Tmax)) for handle in self._handles())
 
     # ---- one ragged batch ---------------------------------------------------------------------------------------------
     def _stream(self):
@@ -365,7 +387,7 @@ class NativePipeline:
         total = max([int(b) + int(n) for b, n in zip(fb, fc)] + [0])
         wav = torch.empty(384 * max(total, 1), dtype=torch.float32, device=self.device)
         fn = self.lib.tts_vocoder_bigvgan if self.kind == "bigvgan" else self.lib.tts_vocoder_hifigan
-        capi.check(fn(self.h, mel_ptr, ld, fb, fc, B, C.c_void_p(wav.data_ptr()), st), "tts_vocoder_" + str(self.kind))
+        capi.check(fn(self.h_voc, mel_ptr, ld, fb, fc, B, C.c_void_p(wav.data_ptr()), st), "tts_vocoder_" + str(self.kind))
         return wav, [(384 * int(b), 384 * int(n)) for b, n in zip(fb, fc)]
 
     @torch.inference_mode()

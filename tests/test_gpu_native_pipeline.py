@@ -186,3 +186,25 @@ def test_pipelined_batches_equal_one_batch_at_a_time(precision):
             assert torch.equal(m_got, m_want), k
         for b0, n in spans:
             assert torch.equal(out["wav"][b0:b0 + n], wav[b0:b0 + n]), (k, b0, n, float((out["wav"][b0:b0 + n] - wav[b0:b0 + n]).abs().max()))
+
+
+def test_mixed_precision_pipeline_is_the_fp32_acoustic_model_plus_the_fp16_vocoder():
+    """NativePipeline(precision="f32", vocoder_precision="f16") (two handles): the mel is bit for bit the fp32 pipeline's - so it
+    carries the fp32 configuration's parity with the reference goldens - and the waveform is bit for bit what the fp16 pipeline's
+    vocoder makes of that mel."""
+    gs = [_gold(n) for n in ("R128", "R97", "R64", "R20")]
+    texts, embs, langs, zs = _inputs(gs)
+    durs = [torch.from_numpy(g["gold_durations"]) for g in gs]
+    ac_sd, voc_sd = fw.acoustic_state_dict(), fw.bigvgan_state_dict()
+    mixed = native.NativePipeline(ac_sd, voc_sd, "bigvgan", DEV, precision="f32", vocoder_precision="f16")
+    exact = native.NativePipeline(ac_sd, voc_sd, "bigvgan", DEV, precision="f32")
+    half = native.NativePipeline(ac_sd, voc_sd, "bigvgan", DEV, precision="f16")
+    out = mixed.forward(texts, embs, langs, durations=durs, z_noise=zs)
+    ref = exact.forward(texts, embs, langs, durations=durs, z_noise=zs, vocode=False)
+    for m_got, m_want, g in zip(out["mel"], ref["mel"], gs):
+        assert torch.equal(m_got, m_want)
+        assert np.abs(m_got.cpu().numpy() - g["mel"]).mean() < 1e-4  # the north-star bound, against the reference's own output
+    wav, rag = half.vocode(ref["mel_packed"], ref["rag_mel"])
+    for (b0, n), (b1, n1) in zip(out["wav_spans"], zip(rag.begins, rag.lengths)):
+        assert n == n1 and torch.equal(out["wav"][b0:b0 + n], wav[b1:b1 + n1])
+    assert mixed.workspace_bytes(4, 128, 640) > 0

@@ -14,6 +14,7 @@ python3 $R/bench.py --dtype fp32 --no-cpu-baseline > $O/bench_fp32.json 2>/dev/n
 python3 $R/bench.py --vocoder hifigan --no-cpu-baseline > $O/bench_bf16_hifigan.json 2>/dev/null
 python3 $R/bench.py --sequencer python --no-cpu-baseline > $O/bench_bf16_python_sequencer.json 2>/dev/null
 python3 $R/bench.py --no-overlap --no-cpu-baseline > $O/bench_bf16_one_stream.json 2>/dev/null
+python3 $R/bench.py --dtype mixed --no-cpu-baseline > $O/bench_mixed_f32_f16.json 2>/dev/null
 python3 $R/tools/latency_configs.py > $O/latency_configs.jsonl 2>/dev/null
 python3 $R/tools/stage_times.py > $O/stage_times_bf16.txt 2>/dev/null
 python3 $R/tools/conv_shapes.py > $O/conv_shapes_bf16.txt 2>/dev/null
