@@ -129,6 +129,7 @@ struct SnakeFir {
         a1 = gen_up(f, 1, frame0 + w, T, lane);
       }
     }
+#ifdef SNAKE_SIN2  // (A/B switch: the five-operation form u + inv_b sin^2(u e^alpha))
     const f32x4v z = {0.f, 0.f, 0.f, 0.f};
     const f32x4v u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, x), z, 0, 0, 0);
     const f32x4v u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, x), z, 0, 0, 0);
@@ -140,6 +141,23 @@ struct SnakeFir {
       s[r] = fmaf(inv_b, sn * sn, u);
     }
     return pack8(s);
+#else
+    // u + b sin^2(theta) = (u + b/2) - (b/2) cos(2 theta), theta = u e^alpha: the up-sampler's accumulators START from b/2 (a free add),
+    // the phase comes out of one fma ((u + b/2) (e^alpha / pi) - (b/2) (e^alpha / pi), in revolutions), and the result out of one
+    // more: four vector operations per sample instead of five - in a kernel whose first limit is vector issue.
+    const float hb = 0.5f * inv_b, er2 = 2.0f * er, c0 = -hb * er2;
+    const f32x4v z = {hb, hb, hb, hb};
+    const f32x4v u0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a0), __builtin_bit_cast(f16x8, x), z, 0, 0, 0);
+    const f32x4v u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1), __builtin_bit_cast(f16x8, x), z, 0, 0, 0);
+    float s[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float up = r < 4 ? u0[r] : u1[r - 4];  // u + b/2
+      const float cs = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(fmaf(up, er2, c0)));  // v_cos takes revolutions
+      s[r] = fmaf(-hb, cs, up);
+    }
+    return pack8(s);
+#endif
   }
 
   // everything a run needs from rows other wavefronts will overwrite: call before the workgroup barrier that precedes sweep()
