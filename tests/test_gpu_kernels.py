@@ -524,3 +524,40 @@ def test_fused_feed_forward(gpu, cpu, compute, rows, hidden, post):
         two = run(gpu, lambda t: t.to("cuda:0").contiguous(), fused=False)
         torch.cuda.synchronize()
         close(g.cpu(), two.cpu(), TOL[compute])
+
+
+def test_concurrent_fused_residual_steps_do_not_share_work_queues(gpu):
+    """Two tts_resblock_step launches in flight at once on two streams (each draws its tiles from its own queue slot), several times
+    over: every output is bit for bit what the same launch produces alone."""
+    dev = "cuda:0"
+    filt = torch.from_numpy(packing.kaiser_sinc_filter12()).to(dev)
+    cases = []
+    for c, k, dil, lengths, seed in ((64, 7, 3, [9000, 4000, 333], 1), (32, 3, 1, [20000, 77], 2)):
+        w1 = rnd(c, c, k, seed=seed, scale=1.0 / np.sqrt(c * k)).numpy()
+        w2 = rnd(c, c, k, seed=seed + 10, scale=1.0 / np.sqrt(c * k)).numpy()
+        b = rnd(c, seed=seed + 20, scale=0.1).numpy()
+        rag = Ragged(lengths, gpu.device, align=2)
+        c1 = packing.pack_conv(w1, b, gpu.device, dil=dil, bf16="f16")
+        c2 = packing.pack_conv(w2, b, gpu.device, dil=1, bf16="f16")
+        x = rnd(rag.total_rows, c, seed=seed + 30).to(dev).to(torch.float16)
+        sn = (rnd(c, seed=seed + 40, scale=0.3).to(dev), rnd(c, seed=seed + 50, scale=0.3).to(dev))
+        cases.append((c1, c2, x, rag, sn))
+    run = lambda cs, y: gpu.resblock_step(cs[0], cs[1], cs[2], y, cs[3], capi.PRE_SNAKE, 0.1, cs[4], cs[4], filt)
+    alone = []
+    for cs in cases:
+        y = torch.zeros_like(cs[2])
+        run(cs, y)
+        alone.append(y)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for _ in range(5):
+        outs = [torch.zeros_like(cs[2]) for cs in cases]
+        for st, cs, y in zip(streams, cases, outs):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                run(cs, y)
+                run(cs, y)  # (the second launch of a stream follows the first: same result)
+        torch.cuda.synchronize()
+        for y, want, rag in zip(outs, alone, (cs[3] for cs in cases)):
+            rows = torch.cat([torch.arange(b0, b0 + n) for b0, n in zip(rag.begins, rag.lengths)]).to(dev)
+            assert torch.equal(y[rows], want[rows])
