@@ -114,6 +114,7 @@ PROTOTYPES = {
     "tts_groupnorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _i, _i, _p, _p]),
     "tts_groupnorm_workspace_floats": (C.c_int64, [_i, _i, _i]),
     "tts_relpos_attention": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
+    "tts_relpos_attention_f16": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "tts_dwconv_swish": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _p]),
     "tts_duration_from_log": (C.c_int, [_p, _p, _i, _p]),
     "tts_prosody_control": (C.c_int, [_p, _i, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _p]),
@@ -153,7 +154,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 11  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 12  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

@@ -180,6 +180,192 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention with the three contractions on the 16-bit matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulation) for the
+// 16-bit configurations: 13 MFMAs per 32-key tile and wavefront instead of 104 (the fp32-input MFMA has 1/16 of the rate; at 640
+// frames per utterance the fp32 kernel was the largest item of the acoustic model: 2.7 of 11.7 ms).  q + u, q + v, K, V, the
+// position table and the probabilities are rounded to fp16 (also in the bf16 configuration: scores of magnitude 10 need the 11-bit
+// mantissa); scores, soft-max statistics and the output accumulate in fp32.  Same decomposition and the same transposed products
+// as above; what changes is the operand layout (8 consecutive k per lane and k step):
+//   * K and the table window are staged as fp16 rows [row][feature] (A operands: one ds_read_b128 per k step);
+//   * (q + u)^T, (q + v)^T: 3 x 8 fp16 features of the lane's query per operand (B operands, 12 registers each);
+//   * P^T comes straight out of the S^T accumulator registers again: registers 0..7 of a lane are keys {4 hi + i, 8 + 4 hi + i}
+//     of the tile's first 16, registers 8..15 the same of the second 16 - that IS a B operand of the 16-deep product if the A
+//     operand (V^T) lists its keys in that order, so V is staged transposed, [feature][key slot], with the keys permuted.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int AH_PK = AM_DK + 8;   // fp16 row pitch of K / table rows (112 B: 16-byte aligned, odd number of 16-byte slots)
+constexpr int AH_PV = AM_KT + 8;   // fp16 row pitch of V^T (80 B)
+
+__global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* __restrict__ qkv, int ld_qkv,
+                                                                   const float* __restrict__ ptab, int pmax,
+                                                                   const float* __restrict__ bias_u, const float* __restrict__ bias_v,
+                                                                   float* __restrict__ ctx, int ld_ctx, int heads,
+                                                                   const TtsTile* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) float am_lds[];
+  unsigned short* Ks = reinterpret_cast<unsigned short*>(am_lds);   // [KT][PK]
+  unsigned short* Vt = Ks + AM_KT * AH_PK;                          // [DK][PV]: V^T, keys in operand order
+  unsigned short* Ps = Vt + AM_DK * AH_PV;                          // [PW + 1][PK]
+  float* Gs = reinterpret_cast<float*>(Ps + (AM_PW + 1) * AH_PK);   // [4][64 * GP] per-wave scratch
+
+  const TtsTile t = tiles[blockIdx.x];
+  const int h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
+  const int n = t.seq_end - t.seq_begin;
+  const int qbase = t.row0 - t.seq_begin;
+  const int qw = qbase + wave * 32;
+  const int qi = qw + li;
+  const int qrow = t.seq_begin + (qi < n ? qi : n - 1);
+  const int hd = heads * AM_DK;
+  float* gs = Gs + wave * 64 * AM_GP;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+  // B operands: features 16 ks + 8 hi .. + 7 of (q + u) / (q + v) of the lane's query, fp16
+  bf16x8 qu[AM_DK / 16], qv[AM_DK / 16];
+  {
+    const float* qp = qkv + (size_t)qrow * ld_qkv + h * AM_DK;
+#pragma unroll
+    for (int ks = 0; ks < AM_DK / 16; ++ks) {
+      const int d0 = 16 * ks + 8 * hi;
+      const float4 q0 = *reinterpret_cast<const float4*>(qp + d0), q1 = *reinterpret_cast<const float4*>(qp + d0 + 4);
+      const float4 u0 = *reinterpret_cast<const float4*>(bias_u + h * AM_DK + d0), u1 = *reinterpret_cast<const float4*>(bias_u + h * AM_DK + d0 + 4);
+      const float4 v0 = *reinterpret_cast<const float4*>(bias_v + h * AM_DK + d0), v1 = *reinterpret_cast<const float4*>(bias_v + h * AM_DK + d0 + 4);
+      const u32x4 pu = {pack16<true>(q0.x + u0.x, q0.y + u0.y), pack16<true>(q0.z + u0.z, q0.w + u0.w), pack16<true>(q1.x + u1.x, q1.y + u1.y),
+                        pack16<true>(q1.z + u1.z, q1.w + u1.w)};
+      const u32x4 pv = {pack16<true>(q0.x + v0.x, q0.y + v0.y), pack16<true>(q0.z + v0.z, q0.w + v0.w), pack16<true>(q1.x + v1.x, q1.y + v1.y),
+                        pack16<true>(q1.z + v1.z, q1.w + v1.w)};
+      qu[ks] = __builtin_bit_cast(bf16x8, pu);
+      qv[ks] = __builtin_bit_cast(bf16x8, pv);
+    }
+  }
+  f32x16 o0, o1;  // O^T: rows d (0..31 | 32..63), column = query
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+  const float scale = 1.0f / sqrtf((float)AM_DK);
+
+  for (int j0 = 0; j0 < n; j0 += AM_KT) {
+    __syncthreads();
+    // ---- stage K (rows), V (transposed, keys in operand order) and the table window, fp16 ----
+    for (int e = tid; e < AM_KT * (AM_DK / 4); e += 256) {
+      const int jj = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
+      const int jr = j0 + jj < n ? j0 + jj : n - 1;
+      const float* base = qkv + (size_t)(t.seq_begin + jr) * ld_qkv + h * AM_DK + c4;
+      const float4 kv = *reinterpret_cast<const float4*>(base + hd);
+      const float4 vv = *reinterpret_cast<const float4*>(base + 2 * hd);
+      *reinterpret_cast<uint2*>(Ks + jj * AH_PK + c4) = make_uint2(pack16<true>(kv.x, kv.y), pack16<true>(kv.z, kv.w));
+      // key jj of the tile -> slot of the 16-deep products: k step jj >> 4; inside it lane half ((jj >> 2) & 1), element (jj & 3) + 4 ((jj >> 3) & 1)
+      const int slot = (jj & 16) + 8 * ((jj >> 2) & 1) + (jj & 3) + 4 * ((jj >> 3) & 1);
+      Vt[(c4 + 0) * AH_PV + slot] = f32_to_f16(vv.x);
+      Vt[(c4 + 1) * AH_PV + slot] = f32_to_f16(vv.y);
+      Vt[(c4 + 2) * AH_PV + slot] = f32_to_f16(vv.z);
+      Vt[(c4 + 3) * AH_PV + slot] = f32_to_f16(vv.w);
+    }
+    const int p0 = qbase - j0 - (AM_KT - 1);
+    for (int e = tid; e < (AM_PW + 1) * (AM_DK / 4); e += 256) {
+      const int w = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
+      int pr = pmax - 1 + p0 + w;
+      pr = pr < 0 ? 0 : (pr > 2 * pmax - 2 ? 2 * pmax - 2 : pr);  // only reached by masked keys / discarded queries
+      const float4 pv = *reinterpret_cast<const float4*>(ptab + (size_t)pr * hd + h * AM_DK + c4);
+      *reinterpret_cast<uint2*>(Ps + w * AH_PK + c4) = make_uint2(pack16<true>(pv.x, pv.y), pack16<true>(pv.z, pv.w));
+    }
+    __syncthreads();
+
+    // ---- S^T = K (Q+u)^T, G^T = Pwin (Q+v)^T (this wave's 64-row sub-window): 3 + 6 MFMAs ----
+    f32x16 s, g0, g1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; g0[r] = 0.f; g1[r] = 0.f; }
+    const unsigned short* pw = Ps + (wave * 32) * AH_PK;
+#pragma unroll
+    for (int ks = 0; ks < AM_DK / 16; ++ks) {
+      const bf16x8 ak = *reinterpret_cast<const bf16x8*>(Ks + li * AH_PK + 16 * ks + 8 * hi);
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pw + li * AH_PK + 16 * ks + 8 * hi);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pw + (32 + li) * AH_PK + 16 * ks + 8 * hi);
+      s = mfma16<true>(ak, qu[ks], s);
+      g0 = mfma16<true>(a0, qv[ks], g0);
+      g1 = mfma16<true>(a1, qv[ks], g1);
+    }
+    // through the per-wave scratch: G^T[w][i] at gs[w*GP + i]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int w = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      gs[w * AM_GP + li] = g0[r];
+      gs[(32 + w) * AM_GP + li] = g1[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;  // key row of register r
+      const float bd = gs[(li - jj + 31) * AM_GP + li];
+      float sc = (s[r] + bd) * scale;
+      sc = (j0 + jj < n) ? sc : -INFINITY;
+      s[r] = sc;
+      m_tile = fmaxf(m_tile, sc);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);  // finite: key j0 is valid
+    const float corr = __expf(m_run - m_new);
+    float l_tile = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_new);
+      s[r] = p;
+      l_tile += p;
+    }
+    l_tile += __shfl_xor(l_tile, 32, 64);
+    l_run = l_run * corr + l_tile;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= corr; o1[r] *= corr; }
+
+    // ---- O^T += V^T P^T: two 16-deep k steps; the B operand of step ks is registers 8 ks .. 8 ks + 7 of P^T as fp16 ----
+    const u32x4 pb0 = {pack16<true>(s[0], s[1]), pack16<true>(s[2], s[3]), pack16<true>(s[4], s[5]), pack16<true>(s[6], s[7])};
+    const u32x4 pb1 = {pack16<true>(s[8], s[9]), pack16<true>(s[10], s[11]), pack16<true>(s[12], s[13]), pack16<true>(s[14], s[15])};
+    const int d1 = li < 16 ? 32 + li : 47;  // d = 32..47 valid; rows 48..63 of O^T are discarded
+    o0 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + li * AH_PV + 8 * hi), __builtin_bit_cast(bf16x8, pb0), o0);
+    o1 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + d1 * AH_PV + 8 * hi), __builtin_bit_cast(bf16x8, pb0), o1);
+    o0 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + li * AH_PV + 16 + 8 * hi), __builtin_bit_cast(bf16x8, pb1), o0);
+    o1 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + d1 * AH_PV + 16 + 8 * hi), __builtin_bit_cast(bf16x8, pb1), o1);
+  }
+
+  // ---- ctx[i][h*dk + d] = O^T[d][i] / l : transpose through the scratch so that every row is written contiguously ----
+  const float inv = 1.0f / l_run;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    gs[d * AM_GP + li] = o0[r] * inv;
+    gs[(32 + d) * AM_GP + li] = o1[r] * inv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (qi < n) {
+    float* op = ctx + (size_t)(t.seq_begin + qi) * ld_ctx + h * AM_DK + hi * 24;
+#pragma unroll
+    for (int d = 0; d < 24; d += 4) {
+      float4 v;
+      v.x = gs[(hi * 24 + d + 0) * AM_GP + li];
+      v.y = gs[(hi * 24 + d + 1) * AM_GP + li];
+      v.z = gs[(hi * 24 + d + 2) * AM_GP + li];
+      v.w = gs[(hi * 24 + d + 3) * AM_GP + li];
+      *reinterpret_cast<float4*>(op + d) = v;
+    }
+  }
+}
+
+int relpos_attention_f16(const float* qkv, int ld_qkv, const float* ptab, int pmax, const float* bias_u, const float* bias_v, float* ctx,
+                         int ld_ctx, int heads, int dk, const TtsTile* tiles, int n_tiles, int tile_rows, hipStream_t st) {
+  TTS_CHECK_ARG(dk == AM_DK, "relpos_attention_f16: head dim %d unsupported (48 only)", dk);
+  TTS_CHECK_ARG(tile_rows == AM_QT, "relpos_attention_f16: tile table must use %d rows, got %d", AM_QT, tile_rows);
+  TTS_CHECK_ARG((ld_qkv & 3) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ptab & 15) == 0 && ((uintptr_t)bias_u & 15) == 0 &&
+                    ((uintptr_t)bias_v & 15) == 0,
+                "relpos_attention_f16: alignment");
+  TTS_CHECK_ARG((ld_ctx & 3) == 0 && ((uintptr_t)ctx & 15) == 0, "relpos_attention_f16: ctx alignment");
+  if (n_tiles == 0) return TTS_OK;
+  const size_t lds = (size_t)(AM_KT * AH_PK + AM_DK * AH_PV + (AM_PW + 1) * AH_PK) * 2 + (size_t)4 * 64 * AM_GP * sizeof(float);
+  hipLaunchKernelGGL(relpos_attention_f16_kernel, dim3(n_tiles, heads), dim3(256), lds, st, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx,
+                     heads, tiles);
+  return launch_status("relpos_attention_f16");
+}
+
 int relpos_attention_mfma(const float* qkv, int ld_qkv, const float* ptab, int pmax, const float* bias_u, const float* bias_v,
                           float* ctx, int ld_ctx, int heads, int dk, const TtsTile* tiles, int n_tiles, int tile_rows, hipStream_t st) {
   TTS_CHECK_ARG(dk == AM_DK, "relpos_attention: head dim %d unsupported (48 only)", dk);

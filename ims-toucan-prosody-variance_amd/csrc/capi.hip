@@ -35,6 +35,8 @@ int relpos_attention(const float*, int, const float*, int, const float*, const f
                      int, hipStream_t);
 int relpos_attention_mfma(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
                           int, hipStream_t);
+int relpos_attention_f16(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
+                          int, hipStream_t);
 int dwconv_swish(const float*, int, float*, int, const float*, const float*, int, int, const TtsTile*, int, int, hipStream_t);
 int duration_from_log(const float*, int*, int, hipStream_t);
 int prosody_control(const float*, int, float*, float*, int*, const int*, const int*, int, float, float, float, float, hipStream_t);
@@ -117,6 +119,12 @@ int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, in
   if (tile_rows == 128)
     return tts::relpos_attention_mfma(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
   return tts::relpos_attention(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
+}
+
+int tts_relpos_attention_f16(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u, const float* bias_v,
+                             float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk, const TtsTile* tiles, int32_t n_tiles,
+                             int32_t tile_rows, tts_stream_t stream) {
+  return tts::relpos_attention_f16(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
 }
 
 int tts_dwconv_swish(const float* x, int32_t ldx, float* y, int32_t ldy, const float* w, const float* b, int32_t c, int32_t k,

@@ -112,6 +112,7 @@ struct Handle {
   int small_tile_blocks = 1536;
   bool no_fused_wavenet = false;  // TOUCAN_NO_FUSED_WAVENET: A/B switch, same meaning as in engine.py
   bool no_fused_ffn = false;      // TOUCAN_NO_FUSED_FFN: likewise
+  bool no_f16_attention = false;  // TOUCAN_NO_F16_ATTENTION: likewise
   // relative position tables [block][2 pmax - 1][192] of the two Conformer stacks, built from the uploaded sinusoid table
   float* ptab[2] = {nullptr, nullptr};
   int pmax = 0;
@@ -504,7 +505,10 @@ int conformer(Handle* h, int stack, float* x, const Layout& l, Arena& a, hipStre
     // relative-position self-attention (:93-116)
     TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[1], b.ln_b[1], R, ATT, 1e-12f, st));
     TTS_TRY(conv(h, b.qkv, T2(ln, ATT), T2(qkv, 3 * ATT), l, st));
-    TTS_TRY(tts_relpos_attention(qkv, 3 * ATT, h->ptab[stack] + bi * prow, h->pmax, b.u, b.v, ctx, ATT, HEADS, DK, t128.dev, t128.n, 128, st));
+    if (b16 == 16 && !h->no_f16_attention)  // (16-bit configurations: the contractions on the fp16 matrix cores)
+      TTS_TRY(tts_relpos_attention_f16(qkv, 3 * ATT, h->ptab[stack] + bi * prow, h->pmax, b.u, b.v, ctx, ATT, HEADS, DK, t128.dev, t128.n, 128, st));
+    else
+      TTS_TRY(tts_relpos_attention(qkv, 3 * ATT, h->ptab[stack] + bi * prow, h->pmax, b.u, b.v, ctx, ATT, HEADS, DK, t128.dev, t128.n, 128, st));
     TTS_TRY(conv(h, b.out, T2(ctx, ATT), T2(x, ATT), l, st, res1));
     // convolution module (:119-125, Convolution.py:31-55)
     TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[2], b.ln_b[2], R, ATT, 1e-12f, st));
@@ -573,6 +577,7 @@ int pipeline_create(const TtsConfig* cfg, Handle** out) {
   if (cfg->small_tile_blocks > 0) h->small_tile_blocks = cfg->small_tile_blocks;
   h->no_fused_wavenet = getenv("TOUCAN_NO_FUSED_WAVENET") != nullptr;
   h->no_fused_ffn = getenv("TOUCAN_NO_FUSED_FFN") != nullptr;
+  h->no_f16_attention = getenv("TOUCAN_NO_F16_ATTENTION") != nullptr;
   *out = h;
   return TTS_OK;
 }

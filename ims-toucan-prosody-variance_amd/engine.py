@@ -220,12 +220,13 @@ class Ops:
                                           ws.data_ptr(), self.stream()), "tts_groupnorm")
         return y
 
-    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag, tile_rows=128):
-        """tile_rows 128: matrix-core kernel (fp32-input MFMA, exact fp32 products); 64: the VALU kernel."""
+    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag, tile_rows=128, f16=False):
+        """tile_rows 128: matrix-core kernel (fp32-input MFMA, exact fp32 products; f16: the fp16-MFMA form of the 16-bit
+        configurations); 64: the VALU kernel."""
         tiles, n = rag.tiles(tile_rows)
-        capi.check(self.lib.tts_relpos_attention(qkv.data_ptr(), _ld(qkv), ptab.data_ptr(), pmax, bias_u.data_ptr(), bias_v.data_ptr(),
-                                                 ctx.data_ptr(), _ld(ctx), HEADS, DK, tiles.data_ptr(), n, tile_rows, self.stream()),
-                   "tts_relpos_attention")
+        fn, name = (self.lib.tts_relpos_attention_f16, "tts_relpos_attention_f16") if f16 else (self.lib.tts_relpos_attention, "tts_relpos_attention")
+        capi.check(fn(qkv.data_ptr(), _ld(qkv), ptab.data_ptr(), pmax, bias_u.data_ptr(), bias_v.data_ptr(), ctx.data_ptr(), _ld(ctx), HEADS, DK,
+                      tiles.data_ptr(), n, tile_rows, self.stream()), name)
         return ctx
 
     def dwconv_swish(self, x, y, w, b, c, k, rag):
@@ -323,6 +324,9 @@ class GraphCache:
                 static[k].copy_(v)
         graph.replay()
         return outs
+
+
+NO_F16_ATTENTION = bool(os.environ.get("TOUCAN_NO_F16_ATTENTION"))  # (A/B switch, csrc/pipeline.hip reads the same variable)
 
 
 class ConformerWeights:
@@ -501,7 +505,7 @@ class AcousticEngine:
                 ops.conv(blk["feed_forward_macaron.w2"], hid, x, rag, alpha=0.5, res=x)
             ops.layernorm(x, ln, *blk["norm_mha"], R, ATT)
             ops.conv(blk["qkv"], ln, qkv, rag)
-            ops.attention(qkv, cw.ptabs[li], cw.pmax, blk["u"], blk["v"], ctx, rag)
+            ops.attention(qkv, cw.ptabs[li], cw.pmax, blk["u"], blk["v"], ctx, rag, f16=self.precision != "f32" and not NO_F16_ATTENTION)
             ops.conv(blk["out"], ctx, x, rag, res=x)
             ops.layernorm(x, ln, *blk["norm_conv"], R, ATT)
             ops.conv(blk["pw1"], ln, glu, rag)

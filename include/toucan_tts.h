@@ -222,6 +222,12 @@ int64_t tts_groupnorm_workspace_floats(int32_t n_seq, int32_t max_len, int32_t g
 int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u,
                          const float* bias_v, float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk,
                          const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
+/* The same attention for the 16-bit configurations: the three contractions on v_mfma_f32_32x32x16_f16 (q + u, q + v, k, v, the
+ * table and the probabilities rounded to fp16 - in the bf16 configuration too; fp32 scores, statistics and output).  Same
+ * arguments; tile_rows must be 128. */
+int tts_relpos_attention_f16(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u,
+                             const float* bias_v, float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk,
+                             const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
 
 /* Depthwise conv over time (k taps, zero padded per utterance) + folded BatchNorm(eval) + Swish on the
  * GLU output. Layers/Convolution.py:50-51, Swish.py:18.  w: [k][c] (BN folded), b: [c]. */
@@ -379,7 +385,7 @@ int tts_synthesize_batch(TtsHandle* h, const float* text, const float* utt_emb, 
 const char* tts_last_error(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 11
+#define TTS_ABI_VERSION 12
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -428,10 +428,16 @@ class Emulator:
             _mat(y, r1, c, ldy)[r0:r1] = out.astype(np.float32)
         return 0
 
-    def tts_relpos_attention(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream):
+    def tts_relpos_attention_f16(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream):
+        """fp16 rounding points as in relpos_attention_f16_kernel: q + u, q + v, k, v, the table -> fp16; the probabilities
+        exp(s - max) -> fp16 before the product with v (the normaliser sums the unrounded ones)."""
+        return self.tts_relpos_attention(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream, f16=True)
+
+    def tts_relpos_attention(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream, f16=False):
         self._count("relpos_attention")
         hd = heads * dk
-        P = _mat(ptab, 2 * pmax - 1, hd, hd).astype(np.float64)
+        r16 = (lambda a: _round16(np.asarray(a, dtype=np.float32), True).astype(np.float64)) if f16 else (lambda a: a)
+        P = r16(_mat(ptab, 2 * pmax - 1, hd, hd).astype(np.float64))
         u = _arr(bias_u, hd).astype(np.float64)
         v = _arr(bias_v, hd).astype(np.float64)
         for sb, se, sid in _seqs_from_tiles(_tiles(tiles, n_tiles)):
@@ -443,11 +449,11 @@ class Emulator:
             out = np.zeros((n, hd))
             for h in range(heads):
                 sl = slice(h * dk, (h + 1) * dk)
-                ac = (q[:, sl] + u[sl]) @ k[:, sl].T
-                bd = np.einsum("id,ijd->ij", q[:, sl] + v[sl], P[rel][:, :, sl])
+                ac = r16((q[:, sl] + u[sl]).astype(np.float32)) @ r16(k[:, sl]).T
+                bd = np.einsum("id,ijd->ij", r16((q[:, sl] + v[sl]).astype(np.float32)), P[rel][:, :, sl])
                 s = (ac + bd) / math.sqrt(dk)
                 s = np.exp(s - s.max(1, keepdims=True))
-                out[:, sl] = (s / s.sum(1, keepdims=True)) @ val[:, sl]
+                out[:, sl] = (r16(s) @ r16(val[:, sl])) / s.sum(1, keepdims=True)
             _mat(ctx, se, hd, ld_ctx)[sb:se] = out.astype(np.float32)
         return 0
 

@@ -255,6 +255,27 @@ def test_relpos_attention(gpu, cpu, lengths, tile_rows):
     close(*both(gpu, cpu, run), tol=5e-5)
 
 
+@pytest.mark.parametrize("lengths", [[640, 37, 128, 1], [129], [700]])
+def test_relpos_attention_f16(gpu, cpu, lengths):
+    """tts_relpos_attention_f16 (the three contractions on the fp16 matrix cores) against the emulator with the same rounding points,
+    and against the exact fp32 kernel within the fp16 tolerance."""
+    pmax = 700
+
+    def run(ops, to, f16=True):
+        rag = Ragged(lengths, ops.device, align=2)
+        qkv = to(rnd(rag.total_rows, 576, seed=1, scale=0.7))
+        ptab = to(rnd(2 * pmax - 1, 192, seed=2, scale=0.5))
+        ctx = to(torch.zeros(rag.total_rows, 192))
+        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, 128, f16=f16)
+    g, c = both(gpu, cpu, run)
+    rag = Ragged(lengths, "cpu", align=2)
+    rows = torch.cat([torch.arange(b, b + n) for b, n in zip(rag.begins, rag.lengths)])
+    close(g.cpu()[rows], c[rows], tol=1e-3)
+    exact = run(gpu, lambda t: t.to("cuda:0").contiguous(), f16=False)
+    torch.cuda.synchronize()
+    close(g.cpu()[rows], exact.cpu()[rows], tol=TOL[capi.COMPUTE_F16])
+
+
 @pytest.mark.parametrize("k", [7, 31])
 def test_dwconv_swish(gpu, cpu, k):
     def run(ops, to):
