@@ -92,6 +92,7 @@ class TtsConfig(C.Structure):
 
 
 IO_X_BF16, IO_Y_BF16, IO_RES_BF16, IO_F16 = 1, 2, 4, 8
+IO_SPLIT_K = 16  # tts_conv1d, fp32: the caller accepts the split-K form on small grids (the acoustic model does)
 
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
 PROTOTYPES = {

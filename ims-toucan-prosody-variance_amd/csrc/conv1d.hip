@@ -17,7 +17,9 @@
 //
 // Tile forms (conv1d_dispatch): 128x128 / 128x96 / 128x64 / 256x32 by output width ("regular"); 64x64 and 64x128 tiles with a
 // double-buffered, register-prefetched window when the host asks for 64-row tiles ("small-batch form": grids that would
-// leave the chip idle); and gemm_rows_kernel, an LDS-free operand stream for 1-tap convs in the small-batch form.  All share
+// leave the chip idle); gemm_rows_kernel, an LDS-free operand stream for 1-tap convs in the small-batch form; and
+// conv_splitk_f32_kernel, 32 x 32 tiles with the contraction split over the four wavefronts, for fp32 grids of a few workgroups
+// (batch 1).  All share
 // conv_epilogue (bias, per-utterance vector, pre-add, activation, GLU / gated / coupling, residual, accumulate, bf16 I/O).
 //
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
@@ -663,6 +665,141 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-K form for fp32 convs whose small-batch grid is still a handful of workgroups (batch 1: the WaveNet in-layer of the
+// flow is 15 workgroups of the 64 x 64 form, and each of its wavefronts then runs 960 dependent v_mfma_f32_32x32x2_f32 -
+// 61 k cycles - alone on its SIMD while 240 CUs idle).  Here a workgroup owns a 32 x 32 output tile (both halves in the dual
+// modes) and its four wavefronts split the contraction: k-step s = (tap, group of 8 channels) goes to wavefront s % 4, every
+// wavefront streams its own operands LDS-free like gemm_rows_kernel (any number of taps: a tap is a row offset, rows outside
+// the utterance contribute zero), the three partial tiles meet in LDS and wavefront 0 runs the shared epilogue.  16x the
+// wavefronts of the 64 x 64 form on the same work.  The accumulation order differs from the other forms (four interleaved
+// partial sums), so a caller opts in per launch with TTS_IO_SPLIT_K: the acoustic model does (results agree to rounding-order
+// level, which is what the fp32 configuration promises); the vocoder does not (chunked == whole, bit for bit).
+// ------------------------------------------------------------------------------------------------
+template <bool DUAL>
+__global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc d) {
+  constexpr int NH = DUAL ? 2 : 1;
+#ifndef TTS_SPLITK_DEPTH
+#define TTS_SPLITK_DEPTH 4
+#endif
+  constexpr int DEPTH = TTS_SPLITK_DEPTH;  // k-steps in flight per wavefront
+  constexpr int L = 1 + 4 * NH;      // loads per k-step
+  __shared__ float part[3][NH][16][64];
+  const TtsTile tile = d.tiles[blockIdx.x >> 1];
+  const int sub = blockIdx.x & 1;    // which 32-row half of the table's 64-row tile
+  if (tile.row0 + sub * 32 >= tile.seq_end) return;  // (the whole workgroup: nothing to write)
+  const int n0 = blockIdx.y * 32;
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 31, lk = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int orow = tile.row0 + sub * 32 + lrow;  // this lane's A row (before the tap offset)
+  const int col = n0 + lrow;
+
+  f32x16 acc[NH][1][1];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][0][0][r] = 0.0f;
+
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  auto u2f = [](unsigned int bits) __attribute__((always_inline)) { return __builtin_bit_cast(float, bits); };
+#define TTS_GLOAD128(dst_, ptr_) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define TTS_GLOAD32(dst_, ptr_) asm volatile("global_load_dword %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
+#define TTS_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
+#define TTS_PIN(r_) asm volatile("" : "+v"(r_))
+  const int G = d.cin >> 3;                       // groups of 8 channels per tap (dispatch: cin % 8 == 0)
+  const int S = d.taps * G;                       // k-steps of the whole contraction
+  const int n_w = S > wave ? (S - wave + 3) >> 2 : 0;  // ... of this wavefront: s = wave, wave + 4, ...
+  int tap_r = 0, g_r = wave;                      // the next step to request (dispatch: G >= 4)
+  const size_t wrow = (size_t)d.wn * 4, whalf = (size_t)d.half_pad * 4;
+  u32x4 a[DEPTH];
+  unsigned int b[NH][DEPTH][4];
+  bool inside[DEPTH];
+  // requests the step (tap_r, g_r) and moves on; past the end it re-requests the last step of the contraction with `inside`
+  // false, i.e. as a row of zeros: the stream stays branch-free, every wait count exact, and the matrix instructions
+  // unconditional (a branch around them makes the compiler shuttle the accumulators between AGPRs and VGPRs at every step)
+  auto request = [&](int slot) __attribute__((always_inline)) {
+    const bool live = tap_r < d.taps;
+    const int tp = live ? tap_r : d.taps - 1, gg = live ? g_r : G - 1;
+    int r = orow + tp * d.dil - d.pad_left;
+    inside[slot] = live && r >= tile.seq_begin && r < tile.seq_end;
+    r = r < tile.seq_begin ? tile.seq_begin : (r >= tile.seq_end ? tile.seq_end - 1 : r);
+    const char* xp = reinterpret_cast<const char*>(d.x) + ((size_t)r * d.ldx + gg * 8 + lk * 4) * 4;
+    const char* wp = reinterpret_cast<const char*>(d.w) + (((size_t)tp * d.cin_pad + gg * 8 + lk * 4) * d.wn + col) * 4;
+    TTS_GLOAD128(a[slot], xp);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) TTS_GLOAD32(b[h][slot][j], wp + j * wrow + h * whalf);
+    g_r += live ? 4 : 0;
+    if (g_r >= G) { g_r -= G; ++tap_r; }
+  };
+  auto arrive = [&](int slot) __attribute__((always_inline)) {
+    TTS_WAIT_VM((DEPTH - 1) * L);
+    TTS_PIN(a[slot]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) TTS_PIN(b[h][slot][j]);
+  };
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) request(u);
+  for (int base = 0; base < n_w; base += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      arrive(u);
+      float av[4], bv[NH][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[j] = inside[u] ? pre_activation(u2f(a[u][j]), d.pre_act, d.pre_slope) : 0.0f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bv[h][j] = u2f(b[h][u][j]);
+      }
+#ifdef TTS_SPLITK_NO_MFMA  // diagnostic build: the operand stream alone
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[h][0][0][j] += av[j] * bv[h][j];
+#else
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[h][j], acc[h][0][0], 0, 0, 0);
+#endif
+#ifdef TTS_SPLITK_NO_LOADS  // diagnostic build: the matrix instructions alone (operands of the first DEPTH steps, reused)
+      if (base + u + DEPTH >= n_w) request(u);
+#else
+      request(u);
+#endif
+    }
+  }
+  TTS_WAIT_VM(0);  // drain the tail requests: their destination registers stay allocated (pinned) until here
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) {
+    TTS_PIN(a[u]);
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) TTS_PIN(b[h][u][j]);
+  }
+#undef TTS_GLOAD128
+#undef TTS_GLOAD32
+#undef TTS_WAIT_VM
+#undef TTS_PIN
+  if (wave != 0) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave - 1][h][r][lane] = acc[h][0][0][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[h][0][0][r] = ((acc[h][0][0][r] + part[0][h][r][lane]) + part[1][h][r][lane]) + part[2][h][r][lane];
+  conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, sub, 0, lrow, lk, acc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // shape -> tile configuration
 // ------------------------------------------------------------------------------------------------
 enum ConvShape { S_128x128, S_128x96, S_128x64, S_256x32, S_D128x96, S_64x64, S_D64x64, S_64x128 };
@@ -755,6 +892,22 @@ static bool gemm_rows_ok(const TtsConvDesc& d) {
   return std::getenv("TOUCAN_NO_GEMM_ROWS") == nullptr;  // escape hatch for A/B measurements
 }
 
+// the split-K form: fp32, opted in by the caller (TTS_IO_SPLIT_K), a grid of at most 128 workgroups in the 64 x 64 form and a
+// contraction deep enough to split (>= 256 products per output)
+static bool splitk_ok(const TtsConvDesc& d, int cols) {
+  if (d.compute != 0 || !(d.io_flags & TTS_IO_SPLIT_K) || (d.io_flags & TTS_IO_X_BF16) || d.pre_act == TTS_PRE_SNAKE) return false;
+  if ((d.cin & 7) != 0 || d.cin < 32 || (d.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0 || (cols & 31) != 0) return false;
+  if ((long long)d.taps * d.cin < 256 || (long long)d.n_tiles * (cols / 64) > 128) return false;
+  return std::getenv("TOUCAN_NO_SPLIT_K") == nullptr;  // escape hatch for A/B measurements
+}
+
+static int launch_splitk(const TtsConvDesc& d, int cols, hipStream_t st) {
+  dim3 grid(2 * d.n_tiles, cols / 32), block(256);
+  if (d.mode != TTS_MODE_LINEAR) hipLaunchKernelGGL(conv_splitk_f32_kernel<true>, grid, block, 0, st, d);
+  else hipLaunchKernelGGL(conv_splitk_f32_kernel<false>, grid, block, 0, st, d);
+  return launch_status("conv1d (split-K)");
+}
+
 static int launch_gemm_rows(const TtsConvDesc& d, hipStream_t st) {
   const bool dual = d.mode != TTS_MODE_LINEAR, xb = d.io_flags & TTS_IO_X_BF16;
   const int cols = dual ? d.half_pad : d.wn;
@@ -795,6 +948,7 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.tile_rows == bm, "conv1d: tile table built for %d rows, kernel needs %d", d.tile_rows, bm);
   TTS_CHECK_ARG(cols % bn == 0 && cols >= d.cout, "conv1d: packed width %d not a multiple of the N tile %d (cout %d)", cols, bn, d.cout);
   TTS_CHECK_ARG(d.mode == TTS_MODE_LINEAR || d.wn == 2 * d.half_pad, "conv1d: dual mode needs wn == 2*half_pad");
+  if ((s == S_64x64 || s == S_D64x64) && splitk_ok(d, cols)) return launch_splitk(d, cols, st);
   if ((s == S_64x64 || s == S_D64x64) && gemm_rows_ok(d)) return launch_gemm_rows(d, st);
   // Small-batch form with 128-column tiles (four wavefronts side by side) once the grid fills the chip anyway: wide outputs
   // then re-read their activation rows half as often (batch 32: acoustic model +3-5 %); below that the 64-column tiles keep

@@ -110,6 +110,8 @@ struct Handle {
   std::unordered_map<std::string, TileTab> tile_cache;
   std::unordered_map<std::string, int*> bounds_cache;
   int small_tile_blocks = 1536;
+  bool split_k = false;           // set by the acoustic stage entries, cleared by the vocoder's: fp32 convs of the acoustic model may
+                                  // take the split-K form on small grids (TTS_IO_SPLIT_K; the vocoder keeps chunked == whole bit for bit)
   bool no_fused_wavenet = false;  // TOUCAN_NO_FUSED_WAVENET: A/B switch, same meaning as in engine.py
   bool no_fused_ffn = false;      // TOUCAN_NO_FUSED_FFN: likewise
   bool no_f16_attention = false;  // TOUCAN_NO_F16_ATTENTION: likewise
@@ -359,6 +361,7 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
   const bool any16 = x.bits == 16 || y.bits == 16 || (o.res.p && o.res.bits == 16);
   d.io_flags = (x.bits == 16 ? TTS_IO_X_BF16 : 0) | (y.bits == 16 ? TTS_IO_Y_BF16 : 0) | ((o.res.p && o.res.bits == 16) ? TTS_IO_RES_BF16 : 0) |
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
+  if (h->split_k && d.compute == TTS_COMPUTE_F32 && tile_rows == 64 && tile_rows == cw.small_tile_rows) d.io_flags |= TTS_IO_SPLIT_K;
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
     const bool dual = cw.mode != TTS_MODE_LINEAR;
@@ -650,6 +653,7 @@ int pipeline_encoder(Handle* h, const float* text, const float* utt_emb, const i
                      hipStream_t st) {
   TTS_CHECK_ARG(h && text && phone_lengths && B > 0, "tts_encoder: bad arguments");
   TTS_CHECK_ARG(!h->cfg.multispeaker || utt_emb, "tts_encoder: the multi-speaker checkpoint needs utterance embeddings");
+  h->split_k = true;
   h->lp = Layout::make(phone_lengths, B, 1);
   h->B = B;
   h->text = text;
@@ -718,6 +722,7 @@ int pipeline_encoder(Handle* h, const float* text, const float* utt_emb, const i
 // ---- stage A.2: pitch / energy / duration predictors (gold values replace a prediction) --------------------------------
 int pipeline_predictors(Handle* h, const float* gold_pitch, const float* gold_energy, const int* gold_dur, hipStream_t st) {
   TTS_CHECK_ARG(h && h->enc, "tts_variance_predictors: run tts_encoder first");
+  h->split_k = true;
   const int R = h->lp.total, B = h->B;
   Arena& a = h->phone;
   if (h->cfg.multispeaker && !(gold_pitch && gold_energy && gold_dur)) {
@@ -785,6 +790,7 @@ int pipeline_control_regulate(Handle* h, float duration_scale, float pitch_scale
 // ---- stage B.1: decoder + feat_out --------------------------------------------------------------------------------------
 int pipeline_decoder(Handle* h, hipStream_t st) {
   TTS_CHECK_ARG(h && h->dec, "tts_decoder: run tts_control_and_regulate first");
+  h->split_k = true;
   TTS_TRY(conformer(h, 1, h->dec, h->lf, h->frame, st));
   ConvW fo;
   TTS_TRY(conv_of(h, "feat_out", &fo));
@@ -797,6 +803,7 @@ int pipeline_decoder(Handle* h, hipStream_t st) {
 // ---- stage B.2: PostNet + residual -------------------------------------------------------------------------------------
 int pipeline_postnet(Handle* h, hipStream_t st) {
   TTS_CHECK_ARG(h && h->mel0, "tts_postnet: run tts_decoder first");
+  h->split_k = true;
   const Layout& l = h->lf;
   const int RF = l.total;
   Arena& a = h->frame;
@@ -837,6 +844,7 @@ int pipeline_postnet(Handle* h, hipStream_t st) {
 int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
   TTS_CHECK_ARG(h && h->mel == h->cat && h->cat, "tts_postflow: run tts_postnet first");
   TTS_CHECK_ARG(z_noise, "tts_postflow: z_noise is required");
+  h->split_k = true;
   const Layout ls = h->lf.halved();
   const int RF = h->lf.total, RS = RF / 2;
   Arena& a = h->frame;
@@ -931,6 +939,7 @@ int pipeline_vocoder(Handle* h, int kind, const float* mel, int ld_mel, const in
                      hipStream_t st) {
   TTS_CHECK_ARG(h && mel && frame_begins && frame_counts && wav && B > 0, "tts_vocoder: bad arguments");
   TTS_CHECK_ARG(kind == h->cfg.vocoder, "tts_vocoder: the handle was created for vocoder %d, not %d", h->cfg.vocoder, kind);
+  h->split_k = false;
   const bool big = kind == 2;
   Layout l;
   for (int u = 0; u < B; ++u) {

@@ -70,6 +70,7 @@ class Ops:
             raise capi.ToucanHipError(f"device {str(self.device)!r}: libtoucan_hip.so has no CPU path - construct the engines / the "
                                       f"interface with device='cuda' (the reference's default 'cpu' cannot be served)")
         self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
+        self.split_k = False  # the acoustic engine sets it: its fp32 convs may take the split-K form on small grids
         self.small_tile_blocks = int(os.environ.get("TOUCAN_SMALL_TILE_BLOCKS", "1536"))  # regular conv grids below this many workgroups switch to the 64 x 64 small-batch form (0: never)
         self._fir_tabs = {}
         self.default_compute = COMPUTE_F32  # convs whose weights carry a 16-bit copy run on bf16 / fp16 MFMA when this is not COMPUTE_F32
@@ -114,6 +115,8 @@ class Ops:
         # 16-bit tensors in HBM are recognised by dtype (strides are already in elements)
         d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0) \
             | _f16_flag(x, y, res)
+        if self.split_k and d.compute == COMPUTE_F32 and tile_rows == 64 and tile_rows == cw.small_tile_rows:
+            d.io_flags |= capi.IO_SPLIT_K  # same rule as pipeline.hip conv()
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
         if tm is not None and tm.wants(cw, d.compute, tile_rows):
@@ -381,6 +384,8 @@ class AcousticEngine:
         over 18 blocks overflow otherwise)."""
         # pack_only: only the weight preparation (host tensors for native.NativePipeline to upload), no launch machinery
         self.ops = None if pack_only else Ops(device)
+        if self.ops is not None:
+            self.ops.split_k = True
         self.device = torch.device(device) if pack_only else self.ops.device
         self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
         self.bf16 = bool(bf16)  # a 16-bit MFMA configuration (either format)

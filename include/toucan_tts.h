@@ -53,6 +53,8 @@ typedef struct {
 #define TTS_IO_Y_BF16 2
 #define TTS_IO_RES_BF16 4
 #define TTS_IO_F16 8      /* the 16-bit tensors named by the three bits above are IEEE fp16 (compute 2) instead of bf16 */
+#define TTS_IO_SPLIT_K 16 /* tts_conv1d, fp32 only: the caller accepts the split-K form when the grid is a handful of workgroups
+                             (four interleaved partial sums: the result then depends on the grid at rounding-order level) */
 #define TTS_COMPUTE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation */
 #define TTS_COMPUTE_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulation (BASELINE.json configs[2]) */
 #define TTS_COMPUTE_F16 2  /* v_mfma_f32_32x32x16_f16, fp32 accumulation (BASELINE.json configs[4]) */

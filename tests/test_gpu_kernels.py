@@ -108,6 +108,62 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
     close(g, c, TOL[compute])
 
 
+SPLIT_K_CASES = [
+    # cin, cout, k, dil, mode, lengths        (fp32, small form, <= 128 workgroups of the 64 x 64 form, taps * cin >= 256)
+    (192, 384, 5, 1, capi.MODE_GATED, [320]),            # the flow's WaveNet in-layer at batch 1
+    (192, 384, 5, 1, capi.MODE_GATED, [63, 21, 1, 130]),
+    (1536, 192, 1, 1, capi.MODE_LINEAR, [128]),          # second feed-forward conv of an encoder block at batch 1
+    (384, 1536, 1, 1, capi.MODE_LINEAR, [128, 5]),
+    (256, 256, 3, 1, capi.MODE_LINEAR, [70, 33, 1]),     # variance-predictor conv
+    (80, 512, 5, 1, capi.MODE_LINEAR, [100]),            # PostNet input conv: cin 80 < cin_pad 96
+    (264, 128, 7, 3, capi.MODE_LINEAR, [64, 65]),        # 33 channel groups (not a multiple of the four wavefronts), halo 18
+    (192, 384, 1, 1, capi.MODE_GLU, [128, 33]),
+    (192, 160, 3, 1, capi.MODE_COUPLING, [44, 63]),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", SPLIT_K_CASES)
+def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, monkeypatch):
+    """TTS_IO_SPLIT_K (fp32 convs of the acoustic model on grids of a few workgroups): against the emulator, and against the same
+    launch without the flag (rounding order only; the flag must really change the kernel: the results differ in the last bits)."""
+    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
+    b = rnd(cout, seed=2, scale=0.1).numpy()
+    dual = mode != capi.MODE_LINEAR
+    co = cout // 2 if dual else cout
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        R = rag.total_rows
+        cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode)
+        assert cw.small_tile_rows == 64
+        x = to(rnd(R, cin, seed=3))
+        y = to(rnd(R, co + 5, seed=4))
+        res = to(rnd(R, co, seed=5))
+        pre = to(rnd(R, 2 * co if dual else co, seed=6))
+        sv = to(rnd(len(lengths), co, seed=7))
+        aux = to(rnd(R, co, seed=8)) if mode == capi.MODE_COUPLING else None
+        ops.conv(cw, x, y[:, :co], rag, pre=capi.PRE_LRELU, pre_slope=0.1, act=capi.ACT_TANH, alpha=0.5, seqvec=sv, preadd=pre, res=res,
+                 res_scale=0.25, aux=aux, accumulate=True, compute=capi.COMPUTE_F32)
+        return y
+
+    gpu.small_tile_blocks = 1 << 30
+    try:
+        gpu.split_k = True
+        g, c = both(gpu, cpu, run)
+        gpu.split_k = False
+        plain = run(gpu, lambda t: t.to("cuda:0").contiguous())
+        gpu.split_k = True
+        monkeypatch.setenv("TOUCAN_NO_SPLIT_K", "1")  # the escape hatch gives the other forms back, bit for bit
+        off = run(gpu, lambda t: t.to("cuda:0").contiguous())
+    finally:
+        gpu.small_tile_blocks = 1536
+        gpu.split_k = False
+    close(g, c, 2e-5)
+    close(g, plain, 1e-5)
+    assert not torch.equal(g, plain), "the split-K form did not run"
+    assert torch.equal(off, plain)
+
+
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 257]), (64, 11, 5, [300, 40]), (256, 7, 3, [130, 1, 2]), (128, 3, 5, [64, 8])])
 @pytest.mark.parametrize("compute", ALL_COMPUTE)
 def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compute):

@@ -20,7 +20,10 @@ def main():
     else:
         shapes = [("WN gated k5", 320, 192, 384, 5, capi.MODE_GATED), ("FFN2 dec", 640, 1536, 192, 1, capi.MODE_LINEAR),
                   ("FFN1 dec", 640, 192, 1536, 1, capi.MODE_LINEAR), ("qkv dec", 640, 192, 576, 1, capi.MODE_LINEAR),
-                  ("FFN2 enc", 128, 1536, 192, 1, capi.MODE_LINEAR), ("out enc", 128, 192, 192, 1, capi.MODE_LINEAR)]
+                  ("FFN2 enc", 128, 1536, 192, 1, capi.MODE_LINEAR), ("out enc", 128, 192, 192, 1, capi.MODE_LINEAR),
+                  ("FFN1 enc", 128, 192, 1536, 1, capi.MODE_LINEAR), ("WN res/skip", 320, 192, 384, 1, capi.MODE_LINEAR),
+                  ("pred k3", 128, 256, 256, 3, capi.MODE_LINEAR), ("postnet k5", 640, 512, 512, 5, capi.MODE_LINEAR),
+                  ("dec conv k3", 640, 192, 192, 3, capi.MODE_LINEAR)]
     for name, M, cin, cout, k, mode in shapes:
         rs = np.random.RandomState(0)
         cw = packing.pack_conv((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32), np.zeros(cout, np.float32), dev, mode=mode, bf16=True)
@@ -28,7 +31,8 @@ def main():
         x = torch.randn(rag.total_rows, cin, device=dev)
         y = torch.empty(rag.total_rows, cout // 2 if mode != capi.MODE_LINEAR else cout, device=dev)
         for comp, cname in ((capi.COMPUTE_F32, "f32"), (capi.COMPUTE_BF16, "bf16")):
-            for split in (0,):
+            for split in ((False, True) if comp == capi.COMPUTE_F32 else (False,)):
+                ops.split_k = split  # fp32: also the split-K form the acoustic model opts into (TTS_IO_SPLIT_K)
                 run = lambda: ops.conv(cw, x, y, rag, compute=comp)
                 for _ in range(3):
                     run()
@@ -39,7 +43,7 @@ def main():
                     run()
                 e1.record()
                 torch.cuda.synchronize()
-                print(f"{name:12s} M={M:4d} {cin:4d}->{cout:4d} k={k} {cname:5s}: {1e3 * e0.elapsed_time(e1) / 50:7.1f} us / launch", flush=True)
+                print(f"{name:12s} M={M:4d} {cin:4d}->{cout:4d} k={k} {cname + (' split-K' if split else ''):13s}: {1e3 * e0.elapsed_time(e1) / 50:7.1f} us / launch", flush=True)
 
 
 if __name__ == "__main__":
