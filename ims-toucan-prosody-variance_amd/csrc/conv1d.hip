@@ -24,6 +24,7 @@
 //
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "snake.h"
@@ -68,6 +69,43 @@ struct Elem<false, F16> {
   static __device__ __forceinline__ float cvt(float v) { return v; }
 };
 
+// One output element of the fused epilogue: a / g are the raw accumulators (g: the gate half in the dual modes), ba / bg the
+// biases, sv the per-utterance vector.  Shared by the 32 x 32 and the 16 x 16 accumulator layouts.
+template <bool DUAL>
+__device__ __forceinline__ void epilogue_element(const TtsConvDesc& d, int row, int n, float a, float g, float ba, float bg, float sv, bool io_f16) {
+  float v = a + ba + sv;
+  if (d.preadd) v += d.preadd[(size_t)row * d.ld_preadd + n];
+  if (DUAL) {
+    g += bg;
+    if (d.preadd) g += d.preadd[(size_t)row * d.ld_preadd + d.cout + n];
+    if (d.mode == TTS_MODE_GLU) {
+      v = v * (1.0f / (1.0f + expf(-g)));
+    } else if (d.mode == TTS_MODE_GATED) {
+      v = tanhf(v) * (1.0f / (1.0f + expf(-g)));
+    } else {  // COUPLING
+      v = (d.aux[(size_t)row * d.ld_aux + n] - v) * expf(-g);
+    }
+  } else {
+    if (d.act == TTS_ACT_RELU) v = fmaxf(v, 0.0f);
+    else if (d.act == TTS_ACT_TANH) v = tanhf(v);
+  }
+  v *= d.alpha;
+  if (d.res) {
+    const float rv = (d.io_flags & TTS_IO_RES_BF16) ? load16(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n], io_f16)
+                                                    : d.res[(size_t)row * d.ld_res + n];
+    v += d.res_scale * rv;
+  }
+  if (d.io_flags & TTS_IO_Y_BF16) {
+    unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
+    if (d.accumulate) v += load16(*yp, io_f16);
+    *yp = store16(v, io_f16);
+  } else {
+    float* yp = d.y + (size_t)row * d.ldy + n;
+    if (d.accumulate) v += *yp;
+    *yp = v;
+  }
+}
+
 // Fused epilogue shared by the conv kernels; C/D layout of a 32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 // Wave (wm, wn) of the workgroup owns accumulator tiles [i][j] at rows tile.row0 + (wm*TM + i)*32, columns n0 + (wn*TN + j)*32.
 template <int TM, int TN, int NH, bool DUAL>
@@ -87,39 +125,26 @@ __device__ __forceinline__ void conv_epilogue(const TtsConvDesc& d, const TtsTil
       for (int r = 0; r < 16; ++r) {
         const int row = tile.row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row >= tile.seq_end) continue;
-        float v = acc[0][i][j][r] + ba + sv;
-        if (d.preadd) v += d.preadd[(size_t)row * d.ld_preadd + n];
-        if (DUAL) {
-          float g = acc[NH - 1][i][j][r] + bg;
-          if (d.preadd) g += d.preadd[(size_t)row * d.ld_preadd + d.cout + n];
-          if (d.mode == TTS_MODE_GLU) {
-            v = v * (1.0f / (1.0f + expf(-g)));
-          } else if (d.mode == TTS_MODE_GATED) {
-            v = tanhf(v) * (1.0f / (1.0f + expf(-g)));
-          } else {  // COUPLING
-            v = (d.aux[(size_t)row * d.ld_aux + n] - v) * expf(-g);
-          }
-        } else {
-          if (d.act == TTS_ACT_RELU) v = fmaxf(v, 0.0f);
-          else if (d.act == TTS_ACT_TANH) v = tanhf(v);
-        }
-        v *= d.alpha;
-        if (d.res) {
-          const float rv = (d.io_flags & TTS_IO_RES_BF16) ? load16(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n], io_f16)
-                                                          : d.res[(size_t)row * d.ld_res + n];
-          v += d.res_scale * rv;
-        }
-        if (d.io_flags & TTS_IO_Y_BF16) {
-          unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
-          if (d.accumulate) v += load16(*yp, io_f16);
-          *yp = store16(v, io_f16);
-        } else {
-          float* yp = d.y + (size_t)row * d.ldy + n;
-          if (d.accumulate) v += *yp;
-          *yp = v;
-        }
+        epilogue_element<DUAL>(d, row, n, acc[0][i][j][r], acc[NH - 1][i][j][r], ba, bg, sv, io_f16);
       }
     }
+  }
+}
+
+// The same for one 16x16 accumulator (v_mfma_f32_16x16x4_f32): col = lane&15, row = reg + 4*(lane>>4), at rows row_base.., columns n0..
+template <int NH, bool DUAL>
+__device__ __forceinline__ void conv_epilogue16(const TtsConvDesc& d, const TtsTile& tile, int n0, int row_base, int lane, const f32x4 (&acc)[NH]) {
+  const bool io_f16 = d.io_flags & TTS_IO_F16;
+  const int n = n0 + (lane & 15);
+  if (n >= d.cout) return;
+  const float ba = d.bias ? d.bias[n] : 0.0f;
+  const float bg = (DUAL && d.bias) ? d.bias[d.cout + n] : 0.0f;
+  const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row_base + r + 4 * (lane >> 4);
+    if (row >= tile.seq_end) continue;
+    epilogue_element<DUAL>(d, row, n, acc[0][r], acc[NH - 1][r], ba, bg, sv, io_f16);
   }
 }
 
@@ -671,33 +696,41 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
 // modes) and its four wavefronts split the contraction: k-step s = (tap, group of 8 channels) goes to wavefront s % 4, every
 // wavefront streams its own operands LDS-free like gemm_rows_kernel (any number of taps: a tap is a row offset, rows outside
 // the utterance contribute zero), the three partial tiles meet in LDS and wavefront 0 runs the shared epilogue.  16x the
-// wavefronts of the 64 x 64 form on the same work.  The accumulation order differs from the other forms (four interleaved
+// wavefronts of the 64 x 64 form on the same work; T16 (v_mfma_f32_16x16x4_f32, 16 x 16 tiles, 16 channels per k-step) 64x,
+// for the grids that are still under one workgroup per two CUs in the 32 x 32 form (measured: the fp32 matrix instructions of
+// one wavefront, not the operand stream, set the time - ~50 ns per 32x32x2 - so the only lever is more wavefronts).  The accumulation order differs from the other forms (four interleaved
 // partial sums), so a caller opts in per launch with TTS_IO_SPLIT_K: the acoustic model does (results agree to rounding-order
 // level, which is what the fp32 configuration promises); the vocoder does not (chunked == whole, bit for bit).
 // ------------------------------------------------------------------------------------------------
-template <bool DUAL>
+template <bool DUAL, bool T16>
 __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc d) {
   constexpr int NH = DUAL ? 2 : 1;
+  constexpr int T = T16 ? 16 : 32;   // rows and columns of the workgroup's output tile
+  constexpr int SUBS = 64 / T;       // such row blocks per 64-row tile of the table
+  constexpr int KQ = 64 / T;         // k-slots of one matrix instruction (lane / T)
+  constexpr int GC = 4 * KQ;         // channels per k-step: one float4 per lane feeds four matrix instructions
+  constexpr int AR = T16 ? 4 : 16;   // accumulator registers per lane
 #ifndef TTS_SPLITK_DEPTH
 #define TTS_SPLITK_DEPTH 4
 #endif
-  constexpr int DEPTH = TTS_SPLITK_DEPTH;  // k-steps in flight per wavefront
+  constexpr int DEPTH = TTS_SPLITK_DEPTH;  // k-steps in flight per wavefront (4, 6, 8 measured alike: the stream is not latency-bound)
   constexpr int L = 1 + 4 * NH;      // loads per k-step
-  __shared__ float part[3][NH][16][64];
-  const TtsTile tile = d.tiles[blockIdx.x >> 1];
-  const int sub = blockIdx.x & 1;    // which 32-row half of the table's 64-row tile
-  if (tile.row0 + sub * 32 >= tile.seq_end) return;  // (the whole workgroup: nothing to write)
-  const int n0 = blockIdx.y * 32;
-  const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 31, lk = lane >> 5;
+  using Acc = typename std::conditional<T16, f32x4, f32x16>::type;
+  __shared__ float part[3][NH][AR][64];
+  const TtsTile tile = d.tiles[blockIdx.x / SUBS];
+  const int sub = blockIdx.x % SUBS;
+  if (tile.row0 + sub * T >= tile.seq_end) return;  // (the whole workgroup: nothing to write)
+  const int n0 = blockIdx.y * T;
+  const int tid = threadIdx.x, lane = tid & 63, lrow = lane & (T - 1), kq = lane / T;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int orow = tile.row0 + sub * 32 + lrow;  // this lane's A row (before the tap offset)
+  const int orow = tile.row0 + sub * T + lrow;  // this lane's A row (before the tap offset)
   const int col = n0 + lrow;
 
-  f32x16 acc[NH][1][1];
+  Acc acc[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[h][0][0][r] = 0.0f;
+    for (int r = 0; r < AR; ++r) acc[h][r] = 0.0f;
 
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   auto u2f = [](unsigned int bits) __attribute__((always_inline)) { return __builtin_bit_cast(float, bits); };
@@ -705,10 +738,10 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
 #define TTS_GLOAD32(dst_, ptr_) asm volatile("global_load_dword %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
 #define TTS_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define TTS_PIN(r_) asm volatile("" : "+v"(r_))
-  const int G = d.cin >> 3;                       // groups of 8 channels per tap (dispatch: cin % 8 == 0)
+  const int G = d.cin / GC;                       // k-steps per tap (dispatch: cin % GC == 0, G >= 4)
   const int S = d.taps * G;                       // k-steps of the whole contraction
   const int n_w = S > wave ? (S - wave + 3) >> 2 : 0;  // ... of this wavefront: s = wave, wave + 4, ...
-  int tap_r = 0, g_r = wave;                      // the next step to request (dispatch: G >= 4)
+  int tap_r = 0, g_r = wave;                      // the next step to request
   const size_t wrow = (size_t)d.wn * 4, whalf = (size_t)d.half_pad * 4;
   u32x4 a[DEPTH];
   unsigned int b[NH][DEPTH][4];
@@ -722,8 +755,8 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
     int r = orow + tp * d.dil - d.pad_left;
     inside[slot] = live && r >= tile.seq_begin && r < tile.seq_end;
     r = r < tile.seq_begin ? tile.seq_begin : (r >= tile.seq_end ? tile.seq_end - 1 : r);
-    const char* xp = reinterpret_cast<const char*>(d.x) + ((size_t)r * d.ldx + gg * 8 + lk * 4) * 4;
-    const char* wp = reinterpret_cast<const char*>(d.w) + (((size_t)tp * d.cin_pad + gg * 8 + lk * 4) * d.wn + col) * 4;
+    const char* xp = reinterpret_cast<const char*>(d.x) + ((size_t)r * d.ldx + gg * GC + kq * 4) * 4;
+    const char* wp = reinterpret_cast<const char*>(d.w) + (((size_t)tp * d.cin_pad + gg * GC + kq * 4) * d.wn + col) * 4;
     TTS_GLOAD128(a[slot], xp);
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -753,22 +786,15 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
 #pragma unroll
         for (int h = 0; h < NH; ++h) bv[h][j] = u2f(b[h][u][j]);
       }
-#ifdef TTS_SPLITK_NO_MFMA  // diagnostic build: the operand stream alone
+      // matrix instruction j contracts the channels gg * GC + 4 q + j, q = 0 .. KQ-1 (k-slot q is supplied by the lanes with kq == q)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h][0][0][j] += av[j] * bv[h][j];
-#else
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int h = 0; h < NH; ++h) acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[h][j], acc[h][0][0], 0, 0, 0);
-#endif
-#ifdef TTS_SPLITK_NO_LOADS  // diagnostic build: the matrix instructions alone (operands of the first DEPTH steps, reused)
-      if (base + u + DEPTH >= n_w) request(u);
-#else
+        for (int h = 0; h < NH; ++h) {
+          if constexpr (T16) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[h][j], acc[h], 0, 0, 0);
+          else acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[h][j], acc[h], 0, 0, 0);
+        }
       request(u);
-#endif
     }
   }
   TTS_WAIT_VM(0);  // drain the tail requests: their destination registers stay allocated (pinned) until here
@@ -788,15 +814,22 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[wave - 1][h][r][lane] = acc[h][0][0][r];
+      for (int r = 0; r < AR; ++r) part[wave - 1][h][r][lane] = acc[h][r];
   }
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[h][0][0][r] = ((acc[h][0][0][r] + part[0][h][r][lane]) + part[1][h][r][lane]) + part[2][h][r][lane];
-  conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, sub, 0, lrow, lk, acc);
+    for (int r = 0; r < AR; ++r) acc[h][r] = ((acc[h][r] + part[0][h][r][lane]) + part[1][h][r][lane]) + part[2][h][r][lane];
+  if constexpr (T16) {
+    conv_epilogue16<NH, DUAL>(d, tile, n0, tile.row0 + sub * 16, lane, acc);
+  } else {
+    f32x16 acc32[NH][1][1];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) acc32[h][0][0] = acc[h];
+    conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, sub, 0, lrow, kq, acc32);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -902,9 +935,17 @@ static bool splitk_ok(const TtsConvDesc& d, int cols) {
 }
 
 static int launch_splitk(const TtsConvDesc& d, int cols, hipStream_t st) {
+  const bool dual = d.mode != TTS_MODE_LINEAR;
+  // 16 x 16 tiles while the 32 x 32 grid is at most 128 workgroups (and the channels come in whole groups of 16)
+  if ((d.cin & 15) == 0 && d.cin >= 64 && (long long)2 * d.n_tiles * (cols / 32) <= 128 && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
+    dim3 grid(4 * d.n_tiles, cols / 16), block(256);
+    if (dual) hipLaunchKernelGGL((conv_splitk_f32_kernel<true, true>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((conv_splitk_f32_kernel<false, true>), grid, block, 0, st, d);
+    return launch_status("conv1d (split-K, 16 x 16)");
+  }
   dim3 grid(2 * d.n_tiles, cols / 32), block(256);
-  if (d.mode != TTS_MODE_LINEAR) hipLaunchKernelGGL(conv_splitk_f32_kernel<true>, grid, block, 0, st, d);
-  else hipLaunchKernelGGL(conv_splitk_f32_kernel<false>, grid, block, 0, st, d);
+  if (dual) hipLaunchKernelGGL((conv_splitk_f32_kernel<true, false>), grid, block, 0, st, d);
+  else hipLaunchKernelGGL((conv_splitk_f32_kernel<false, false>), grid, block, 0, st, d);
   return launch_status("conv1d (split-K)");
 }
 

@@ -110,8 +110,8 @@ struct Handle {
   std::unordered_map<std::string, TileTab> tile_cache;
   std::unordered_map<std::string, int*> bounds_cache;
   int small_tile_blocks = 1536;
-  bool split_k = false;           // set by the acoustic stage entries, cleared by the vocoder's: fp32 convs of the acoustic model may
-                                  // take the split-K form on small grids (TTS_IO_SPLIT_K; the vocoder keeps chunked == whole bit for bit)
+  bool split_k = false;           // set by the acoustic stage entries, cleared by the vocoder's: in the fp32 configuration the convs of the
+                                  // acoustic model may take the split-K form on small grids (TTS_IO_SPLIT_K; the vocoder keeps chunked == whole)
   bool no_fused_wavenet = false;  // TOUCAN_NO_FUSED_WAVENET: A/B switch, same meaning as in engine.py
   bool no_fused_ffn = false;      // TOUCAN_NO_FUSED_FFN: likewise
   bool no_f16_attention = false;  // TOUCAN_NO_F16_ATTENTION: likewise
@@ -361,7 +361,10 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
   const bool any16 = x.bits == 16 || y.bits == 16 || (o.res.p && o.res.bits == 16);
   d.io_flags = (x.bits == 16 ? TTS_IO_X_BF16 : 0) | (y.bits == 16 ? TTS_IO_Y_BF16 : 0) | ((o.res.p && o.res.bits == 16) ? TTS_IO_RES_BF16 : 0) |
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
-  if (h->split_k && d.compute == TTS_COMPUTE_F32 && tile_rows == 64 && tile_rows == cw.small_tile_rows) d.io_flags |= TTS_IO_SPLIT_K;
+  // the fp32 configuration only: the fp32 layers of a 16-bit configuration keep one accumulation order at every batch size (an
+  // utterance's result there does not depend on the batch it is in, bit for bit - tests/test_gpu_e2e.py asserts it)
+  if (h->split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32 && tile_rows == 64 && tile_rows == cw.small_tile_rows)
+    d.io_flags |= TTS_IO_SPLIT_K;
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
     const bool dual = cw.mode != TTS_MODE_LINEAR;

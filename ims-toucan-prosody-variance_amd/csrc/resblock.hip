@@ -859,6 +859,21 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #endif
 }
 
+}  // namespace tts
+// Diagnostic (tests/conftest.py calls it after every GPU test): words of the work-queue slots that are not zero once the device
+// is idle.  Every launch must leave its slot clean - a dirty slot would hand the launch that next draws it tickets that start
+// in the middle of a run.  Returns the count (0 = clean), negative on a HIP error.
+extern "C" int tts_diag_queue_nonzero(void) {
+  static unsigned int host[tts::RB_QUEUE_SLOTS][16];
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tts::g_rb_queue), sizeof(host)) != hipSuccess) return -2;
+  int n = 0;
+  for (int s = 0; s < tts::RB_QUEUE_SLOTS; ++s)
+    for (int i = 0; i < 16; ++i) n += host[s][i] != 0;
+  return n;
+}
+namespace tts {
+
 #ifdef RB_DIAG_CLOCK
 }  // namespace tts
 extern "C" int tts_rb_diag_trace(unsigned long long* out, int n_workgroups) {
@@ -870,6 +885,8 @@ namespace tts {
 
 #undef load_slab
 #undef store_slab
+
+static std::atomic<unsigned int> g_rb_launches{0};  // launches of every instantiation so far: the work-queue slot of the next one
 
 template <int C, bool IOB, bool F16, bool MFIR>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
@@ -914,8 +931,9 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   if (fixed_per_cu > 0) per_cu = fixed_per_cu;
   const long resident = (long)cus * per_cu;
   const int grid = (int)(fixed_per_cu < 0 || d.n_tiles < resident ? d.n_tiles : resident);  // (TOUCAN_RB_WG_PER_CU=-1: one workgroup per tile)
-  static std::atomic<unsigned int> launches{0};
-  const int queue_slot = (int)(launches.fetch_add(1, std::memory_order_relaxed) % RB_QUEUE_SLOTS);
+  // (ONE counter for every instantiation of this template: a function-local static would give each channel class its own, and
+  //  two classes launched on two streams would walk the slots in lockstep and share them)
+  const int queue_slot = (int)(g_rb_launches.fetch_add(1, std::memory_order_relaxed) % RB_QUEUE_SLOTS);
   hipLaunchKernelGGL(k, dim3(grid), dim3(RB_THREADS), lds, st, d, queue_slot);
   return launch_status("resblock_step");
 }

@@ -117,15 +117,19 @@ SPLIT_K_CASES = [
     (256, 256, 3, 1, capi.MODE_LINEAR, [70, 33, 1]),     # variance-predictor conv
     (80, 512, 5, 1, capi.MODE_LINEAR, [100]),            # PostNet input conv: cin 80 < cin_pad 96
     (264, 128, 7, 3, capi.MODE_LINEAR, [64, 65]),        # 33 channel groups (not a multiple of the four wavefronts), halo 18
-    (192, 384, 1, 1, capi.MODE_GLU, [128, 33]),
-    (192, 160, 3, 1, capi.MODE_COUPLING, [44, 63]),
+    (384, 384, 1, 1, capi.MODE_GLU, [128, 33]),
+    (192, 256, 3, 1, capi.MODE_COUPLING, [44, 63]),
 ]
 
 
 @pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", SPLIT_K_CASES)
-def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, monkeypatch):
+@pytest.mark.parametrize("tile", [16, 32])
+def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, tile, monkeypatch):
     """TTS_IO_SPLIT_K (fp32 convs of the acoustic model on grids of a few workgroups): against the emulator, and against the same
-    launch without the flag (rounding order only; the flag must really change the kernel: the results differ in the last bits)."""
+    launch without the flag (rounding order only; the flag must really change the kernel: the results differ in the last bits).
+    tile: the 16 x 16 form (taken when the channels come in groups of 16 and the grid is tiny) or the 32 x 32 form alone."""
+    if tile == 32:
+        monkeypatch.setenv("TOUCAN_NO_SPLIT_K16", "1")
     w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
     b = rnd(cout, seed=2, scale=0.1).numpy()
     dual = mode != capi.MODE_LINEAR
