@@ -23,6 +23,7 @@
 // conv_epilogue (bias, per-utterance vector, pre-add, activation, GLU / gated / coupling, residual, accumulate, bf16 I/O).
 //
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -926,11 +927,13 @@ static bool gemm_rows_ok(const TtsConvDesc& d) {
 }
 
 // the split-K form: fp32, opted in by the caller (TTS_IO_SPLIT_K), a grid of at most 128 workgroups in the 64 x 64 form and a
-// contraction deep enough to split (>= 256 products per output)
+// contraction of at least 64 products per output (measured at batch 1 x 128 phonemes, the whole acoustic pass: 6.4 ms with a
+// minimum depth of 256, 5.2 ms with 128, 5.0 ms with 64 - even the 192-deep 1-tap convs are faster on 4-16x the wavefronts)
 static bool splitk_ok(const TtsConvDesc& d, int cols) {
   if (d.compute != 0 || !(d.io_flags & TTS_IO_SPLIT_K) || (d.io_flags & TTS_IO_X_BF16) || d.pre_act == TTS_PRE_SNAKE) return false;
   if ((d.cin & 7) != 0 || d.cin < 32 || (d.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0 || (cols & 31) != 0) return false;
-  if ((long long)d.taps * d.cin < 256 || (long long)d.n_tiles * (cols / 64) > 128) return false;
+  static const int min_depth = std::getenv("TOUCAN_SPLIT_K_MIN") ? std::atoi(std::getenv("TOUCAN_SPLIT_K_MIN")) : 64;  // (A/B runs)
+  if ((long long)d.taps * d.cin < min_depth || (long long)d.n_tiles * (cols / 64) > 128) return false;
   return std::getenv("TOUCAN_NO_SPLIT_K") == nullptr;  // escape hatch for A/B measurements
 }
 
@@ -989,6 +992,9 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.tile_rows == bm, "conv1d: tile table built for %d rows, kernel needs %d", d.tile_rows, bm);
   TTS_CHECK_ARG(cols % bn == 0 && cols >= d.cout, "conv1d: packed width %d not a multiple of the N tile %d (cout %d)", cols, bn, d.cout);
   TTS_CHECK_ARG(d.mode == TTS_MODE_LINEAR || d.wn == 2 * d.half_pad, "conv1d: dual mode needs wn == 2*half_pad");
+  if (d.compute == 0 && std::getenv("TOUCAN_SPLIT_K_LOG"))  // (debugging aid: which form every fp32 launch takes)
+    fprintf(stderr, "conv-f32 cin %d cout %d taps %d tile_rows %d tiles %d cols %d ldx %d flag %d -> splitk %d\n", d.cin, d.cout, d.taps, d.tile_rows,
+            d.n_tiles, cols, d.ldx, (int)((d.io_flags & TTS_IO_SPLIT_K) != 0), (int)((s == S_64x64 || s == S_D64x64) && splitk_ok(d, cols)));
   if ((s == S_64x64 || s == S_D64x64) && splitk_ok(d, cols)) return launch_splitk(d, cols, st);
   if ((s == S_64x64 || s == S_D64x64) && gemm_rows_ok(d)) return launch_gemm_rows(d, st);
   // Small-batch form with 128-column tiles (four wavefronts side by side) once the grid fills the chip anyway: wide outputs

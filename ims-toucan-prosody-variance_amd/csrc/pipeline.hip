@@ -329,6 +329,7 @@ struct ConvOpt {
   const float* aux = nullptr; int ld_aux = 0;
   bool accumulate = false;
   bool fp32_only = false;  // run on the fp32 MFMA path even if a 16-bit copy exists
+  bool no_split_k = false; // never the split-K form (the position tables: their rows must not depend on the table's size)
   const float *snake_alpha = nullptr, *snake_beta = nullptr, *snake_filt = nullptr;
 };
 
@@ -363,7 +364,7 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
   // the fp32 configuration only: the fp32 layers of a 16-bit configuration keep one accumulation order at every batch size (an
   // utterance's result there does not depend on the batch it is in, bit for bit - tests/test_gpu_e2e.py asserts it)
-  if (h->split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32 && tile_rows == 64 && tile_rows == cw.small_tile_rows)
+  if (h->split_k && !o.no_split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32 && tile_rows == 64 && tile_rows == cw.small_tile_rows)
     d.io_flags |= TTS_IO_SPLIT_K;
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
@@ -443,6 +444,7 @@ int ensure_ptabs(Handle* h, hipStream_t st) {
       TTS_TRY(conv_of(h, std::string(s ? "dec." : "enc.") + std::to_string(b) + ".pos", &pos));
       ConvOpt o;
       o.fp32_only = true;
+      o.no_split_k = true;
       TTS_TRY(conv(h, pos, T2(pe->p, ATT), T2(h->ptab[s] + (size_t)b * rows * ATT, ATT), l, st, o));
     }
   h->pmax = pmax;

@@ -84,7 +84,7 @@ class Ops:
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
     def conv(self, cw, x, y, rag, pre=PRE_NONE, pre_slope=0.0, act=ACT_NONE, alpha=1.0, seqvec=None, preadd=None, res=None,
-             res_scale=1.0, aux=None, accumulate=False, compute=None, snake=None):
+             res_scale=1.0, aux=None, accumulate=False, compute=None, snake=None, split_k=True):
         if compute is None:
             compute = self.default_compute
         tile_rows = cw.tile_rows
@@ -115,7 +115,7 @@ class Ops:
         # 16-bit tensors in HBM are recognised by dtype (strides are already in elements)
         d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0) \
             | _f16_flag(x, y, res)
-        if self.split_k and self.default_compute == COMPUTE_F32 and d.compute == COMPUTE_F32 and tile_rows == 64 and tile_rows == cw.small_tile_rows:
+        if split_k and self.split_k and self.default_compute == COMPUTE_F32 and d.compute == COMPUTE_F32 and tile_rows == 64 and tile_rows == cw.small_tile_rows:
             # same rule as pipeline.hip conv(): the fp32 configuration only - the fp32 layers of a 16-bit configuration keep one
             # accumulation order at every batch size (an utterance's result there does not depend on the batch it is in, bit for bit)
             d.io_flags |= capi.IO_SPLIT_K
@@ -482,7 +482,8 @@ class AcousticEngine:
         ops = self.ops
         pe = _dev(packing.rel_pos_encoding(pmax), self.device)
         rag = Ragged.cached([2 * pmax - 1], self.device)
-        cw.ptabs = [ops.conv(blk["pos"], pe, ops.empty(2 * pmax - 1, ATT), rag) for blk in cw.blocks]
+        # (never the split-K form: a table is shared by calls with different pmax, and its rows must not depend on the table's size)
+        cw.ptabs = [ops.conv(blk["pos"], pe, ops.empty(2 * pmax - 1, ATT), rag, split_k=False) for blk in cw.blocks]
         cw.pmax = pmax
 
     # ---- Conformer stack ---------------------------------------------------------------------------

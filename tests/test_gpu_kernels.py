@@ -109,7 +109,7 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
 
 
 SPLIT_K_CASES = [
-    # cin, cout, k, dil, mode, lengths        (fp32, small form, <= 128 workgroups of the 64 x 64 form, taps * cin >= 256)
+    # cin, cout, k, dil, mode, lengths        (fp32, small form, <= 128 workgroups of the 64 x 64 form, taps * cin >= 64)
     (192, 384, 5, 1, capi.MODE_GATED, [320]),            # the flow's WaveNet in-layer at batch 1
     (192, 384, 5, 1, capi.MODE_GATED, [63, 21, 1, 130]),
     (1536, 192, 1, 1, capi.MODE_LINEAR, [128]),          # second feed-forward conv of an encoder block at batch 1
@@ -119,6 +119,8 @@ SPLIT_K_CASES = [
     (264, 128, 7, 3, capi.MODE_LINEAR, [64, 65]),        # 33 channel groups (not a multiple of the four wavefronts), halo 18
     (384, 384, 1, 1, capi.MODE_GLU, [128, 33]),
     (192, 256, 3, 1, capi.MODE_COUPLING, [44, 63]),
+    (192, 576, 1, 1, capi.MODE_LINEAR, [128]),           # q/k/v projection: 192 products per output
+    (80, 384, 1, 1, capi.MODE_LINEAR, [320, 2]),         # the flow's input conv: 80 products, 10 channel groups of 8
 ]
 
 
