@@ -707,7 +707,6 @@ template <bool DUAL, bool T16>
 __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc d) {
   constexpr int NH = DUAL ? 2 : 1;
   constexpr int T = T16 ? 16 : 32;   // rows and columns of the workgroup's output tile
-  constexpr int SUBS = 64 / T;       // such row blocks per 64-row tile of the table
   constexpr int KQ = 64 / T;         // k-slots of one matrix instruction (lane / T)
   constexpr int GC = 4 * KQ;         // channels per k-step: one float4 per lane feeds four matrix instructions
   constexpr int AR = T16 ? 4 : 16;   // accumulator registers per lane
@@ -718,8 +717,9 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
   constexpr int L = 1 + 4 * NH;      // loads per k-step
   using Acc = typename std::conditional<T16, f32x4, f32x16>::type;
   __shared__ float part[3][NH][AR][64];
-  const TtsTile tile = d.tiles[blockIdx.x / SUBS];
-  const int sub = blockIdx.x % SUBS;
+  const int subs = d.tile_rows / T;  // row blocks of this kernel per tile of the table (any of the table's forms: 64, 128, 256 rows)
+  const TtsTile tile = d.tiles[blockIdx.x / subs];
+  const int sub = blockIdx.x % subs;
   if (tile.row0 + sub * T >= tile.seq_end) return;  // (the whole workgroup: nothing to write)
   const int n0 = blockIdx.y * T;
   const int tid = threadIdx.x, lane = tid & 63, lrow = lane & (T - 1), kq = lane / T;
@@ -926,27 +926,27 @@ static bool gemm_rows_ok(const TtsConvDesc& d) {
   return std::getenv("TOUCAN_NO_GEMM_ROWS") == nullptr;  // escape hatch for A/B measurements
 }
 
-// the split-K form: fp32, opted in by the caller (TTS_IO_SPLIT_K), a grid of at most 128 workgroups in the 64 x 64 form and a
+// the split-K form: fp32, opted in by the caller (TTS_IO_SPLIT_K), a grid of at most 128 workgroups if cut into 64 x 64 tiles and a
 // contraction of at least 64 products per output (measured at batch 1 x 128 phonemes, the whole acoustic pass: 6.4 ms with a
 // minimum depth of 256, 5.2 ms with 128, 5.0 ms with 64 - even the 192-deep 1-tap convs are faster on 4-16x the wavefronts)
 static bool splitk_ok(const TtsConvDesc& d, int cols) {
   if (d.compute != 0 || !(d.io_flags & TTS_IO_SPLIT_K) || (d.io_flags & TTS_IO_X_BF16) || d.pre_act == TTS_PRE_SNAKE) return false;
   if ((d.cin & 7) != 0 || d.cin < 32 || (d.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0 || (cols & 31) != 0) return false;
   static const int min_depth = std::getenv("TOUCAN_SPLIT_K_MIN") ? std::atoi(std::getenv("TOUCAN_SPLIT_K_MIN")) : 64;  // (A/B runs)
-  if ((long long)d.taps * d.cin < min_depth || (long long)d.n_tiles * (cols / 64) > 128) return false;
+  if ((long long)d.taps * d.cin < min_depth || (long long)d.n_tiles * (d.tile_rows / 64) * ((cols + 63) / 64) > 128) return false;
   return std::getenv("TOUCAN_NO_SPLIT_K") == nullptr;  // escape hatch for A/B measurements
 }
 
 static int launch_splitk(const TtsConvDesc& d, int cols, hipStream_t st) {
   const bool dual = d.mode != TTS_MODE_LINEAR;
   // 16 x 16 tiles while the 32 x 32 grid is at most 128 workgroups (and the channels come in whole groups of 16)
-  if ((d.cin & 15) == 0 && d.cin >= 64 && (long long)2 * d.n_tiles * (cols / 32) <= 128 && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
-    dim3 grid(4 * d.n_tiles, cols / 16), block(256);
+  if ((d.cin & 15) == 0 && d.cin >= 64 && (long long)d.n_tiles * (d.tile_rows / 32) * (cols / 32) <= 128 && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
+    dim3 grid(d.n_tiles * (d.tile_rows / 16), cols / 16), block(256);
     if (dual) hipLaunchKernelGGL((conv_splitk_f32_kernel<true, true>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((conv_splitk_f32_kernel<false, true>), grid, block, 0, st, d);
     return launch_status("conv1d (split-K, 16 x 16)");
   }
-  dim3 grid(2 * d.n_tiles, cols / 32), block(256);
+  dim3 grid(d.n_tiles * (d.tile_rows / 32), cols / 32), block(256);
   if (dual) hipLaunchKernelGGL((conv_splitk_f32_kernel<true, false>), grid, block, 0, st, d);
   else hipLaunchKernelGGL((conv_splitk_f32_kernel<false, false>), grid, block, 0, st, d);
   return launch_status("conv1d (split-K)");
@@ -994,8 +994,8 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.mode == TTS_MODE_LINEAR || d.wn == 2 * d.half_pad, "conv1d: dual mode needs wn == 2*half_pad");
   if (d.compute == 0 && std::getenv("TOUCAN_SPLIT_K_LOG"))  // (debugging aid: which form every fp32 launch takes)
     fprintf(stderr, "conv-f32 cin %d cout %d taps %d tile_rows %d tiles %d cols %d ldx %d flag %d -> splitk %d\n", d.cin, d.cout, d.taps, d.tile_rows,
-            d.n_tiles, cols, d.ldx, (int)((d.io_flags & TTS_IO_SPLIT_K) != 0), (int)((s == S_64x64 || s == S_D64x64) && splitk_ok(d, cols)));
-  if ((s == S_64x64 || s == S_D64x64) && splitk_ok(d, cols)) return launch_splitk(d, cols, st);
+            d.n_tiles, cols, d.ldx, (int)((d.io_flags & TTS_IO_SPLIT_K) != 0), (int)splitk_ok(d, cols));
+  if (splitk_ok(d, cols)) return launch_splitk(d, cols, st);  // (whatever the table's tile rows: the kernel cuts its own row blocks out of them)
   if ((s == S_64x64 || s == S_D64x64) && gemm_rows_ok(d)) return launch_gemm_rows(d, st);
   // Small-batch form with 128-column tiles (four wavefronts side by side) once the grid fills the chip anyway: wide outputs
   // then re-read their activation rows half as often (batch 32: acoustic model +3-5 %); below that the 64-column tiles keep

@@ -364,7 +364,7 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
   // the fp32 configuration only: the fp32 layers of a 16-bit configuration keep one accumulation order at every batch size (an
   // utterance's result there does not depend on the batch it is in, bit for bit - tests/test_gpu_e2e.py asserts it)
-  if (h->split_k && !o.no_split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32 && tile_rows == 64 && tile_rows == cw.small_tile_rows)
+  if (h->split_k && !o.no_split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32)
     d.io_flags |= TTS_IO_SPLIT_K;
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)

@@ -115,7 +115,7 @@ class Ops:
         # 16-bit tensors in HBM are recognised by dtype (strides are already in elements)
         d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0) \
             | _f16_flag(x, y, res)
-        if split_k and self.split_k and self.default_compute == COMPUTE_F32 and d.compute == COMPUTE_F32 and tile_rows == 64 and tile_rows == cw.small_tile_rows:
+        if split_k and self.split_k and self.default_compute == COMPUTE_F32 and d.compute == COMPUTE_F32:
             # same rule as pipeline.hip conv(): the fp32 configuration only - the fp32 layers of a 16-bit configuration keep one
             # accumulation order at every batch size (an utterance's result there does not depend on the batch it is in, bit for bit)
             d.io_flags |= capi.IO_SPLIT_K

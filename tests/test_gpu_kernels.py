@@ -109,7 +109,7 @@ def test_conv1d(gpu, cpu, cin, cout, k, dil, mode, lengths, compute, form):
 
 
 SPLIT_K_CASES = [
-    # cin, cout, k, dil, mode, lengths        (fp32, small form, <= 128 workgroups of the 64 x 64 form, taps * cin >= 64)
+    # cin, cout, k, dil, mode, lengths        (fp32, <= 128 workgroups if cut into 64 x 64 tiles, taps * cin >= 64)
     (192, 384, 5, 1, capi.MODE_GATED, [320]),            # the flow's WaveNet in-layer at batch 1
     (192, 384, 5, 1, capi.MODE_GATED, [63, 21, 1, 130]),
     (1536, 192, 1, 1, capi.MODE_LINEAR, [128]),          # second feed-forward conv of an encoder block at batch 1
@@ -121,6 +121,9 @@ SPLIT_K_CASES = [
     (192, 256, 3, 1, capi.MODE_COUPLING, [44, 63]),
     (192, 576, 1, 1, capi.MODE_LINEAR, [128]),           # q/k/v projection: 192 products per output
     (80, 384, 1, 1, capi.MODE_LINEAR, [320, 2]),         # the flow's input conv: 80 products, 10 channel groups of 8
+    (256, 80, 5, 1, capi.MODE_LINEAR, [640]),            # no small-batch form (packed width 96): row blocks cut out of 128-row tiles
+    (256, 1, 1, 1, capi.MODE_LINEAR, [128, 9]),          # predictor output: one column of a 256 x 32 tile
+    (192, 160, 1, 1, capi.MODE_COUPLING, [320]),         # coupling conv of the flow (half width 80, packed 96)
 ]
 
 
@@ -141,7 +144,6 @@ def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, tile, m
         rag = Ragged(lengths, ops.device, align=2)
         R = rag.total_rows
         cw = packing.pack_conv(w, b, ops.device, dil=dil, mode=mode)
-        assert cw.small_tile_rows == 64
         x = to(rnd(R, cin, seed=3))
         y = to(rnd(R, co + 5, seed=4))
         res = to(rnd(R, co, seed=5))

@@ -17,11 +17,15 @@ python3 $R/bench.py --no-overlap --no-cpu-baseline > $O/bench_bf16_one_stream.js
 python3 $R/bench.py --dtype mixed --no-cpu-baseline > $O/bench_mixed_f32_f16.json 2>/dev/null
 python3 $R/tools/latency_configs.py > $O/latency_configs.jsonl 2>/dev/null
 python3 $R/tools/stage_times.py > $O/stage_times_bf16.txt 2>/dev/null
+python3 $R/tools/stage_times.py --batch 1 --precision f32 > $O/stage_times_b1_f32.txt 2>/dev/null
+python3 $R/tools/microbench_small.py > $O/microbench_small_f32.txt 2>/dev/null
 python3 $R/tools/conv_shapes.py > $O/conv_shapes_bf16.txt 2>/dev/null
 python3 $R/tools/microbench_ffn.py > $O/microbench_ffn_bf16.txt 2>/dev/null
 echo "[collect] kernel traces"; date
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bf16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/rocprof_bf16.log 2>&1
 cp /tmp/p_bf16/*kernel_stats.csv $O/bench_bf16_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b1 -o r -- python3 $R/tools/latency_configs.py --reps 5 > $O/rocprof_b1.log 2>&1
+cp /tmp/p_b1/*kernel_stats.csv $O/latency_configs_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fp16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --dtype fp16 --pitch-scale 1.3 --energy-scale 0.7 > $O/rocprof_fp16.log 2>&1
 cp /tmp/p_fp16/*kernel_stats.csv $O/bench_fp16_kernel_stats.csv
 echo "[collect] counter passes (separate runs, --kernel-trace only)"; date
@@ -34,5 +38,5 @@ cp /tmp/p_sq/*counter_collection.csv $O/pmc_resblock_SQ.csv
 python3 $R/tools/pmc_traffic.py $O/pmc_resblock_FETCH_SIZE.csv $O/pmc_resblock_WRITE_SIZE.csv $O/pmc_resblock_traffic.json > $O/pmc_traffic_summary.txt
 python3 $R/tools/pmc_sq_summary.py $O/pmc_resblock_SQ.csv $O/pmc_resblock_SQ_summary.json > $O/pmc_sq_summary.txt
 python3 $R/tools/microbench_resblock.py --store bf16 --reps 5 > $O/microbench_resblock_bf16.txt 2>/dev/null
-rm -f $O/pmc_fetch.log $O/pmc_write.log $O/pmc_sq.log $O/rocprof_bf16.log $O/rocprof_fp16.log
+rm -f $O/pmc_fetch.log $O/pmc_write.log $O/pmc_sq.log $O/rocprof_bf16.log $O/rocprof_fp16.log $O/rocprof_b1.log
 echo "[collect] done"; date
