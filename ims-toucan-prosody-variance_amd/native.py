@@ -6,6 +6,7 @@ This is the product path of ``ToucanTTSInterface`` on a GPU.  The Python-sequenc
 tests, for HIP-graph capture and for the CPU host-logic tests that drive the numpy ABI emulator.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -46,7 +47,8 @@ class NativePipeline:
             voc = engine.VocoderEngine(vocoder_sd, vocoder_kind, "cpu", precision=self.vocoder_precision, pack_only=True)
         kind_code = {None: 0, "hifigan": 1, "bigvgan": 2}[vocoder_kind]
         post_b = float(voc.post_b) if voc is not None else 0.0
-        cfg = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), 0 if split else kind_code, compute, 0, post_b)
+        stb = int(os.environ.get("TOUCAN_SMALL_TILE_BLOCKS", "0"))  # same A/B switch as engine.Ops (0: the library's default, 1536)
+        cfg = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), 0 if split else kind_code, compute, stb, post_b)
         self.h = C.c_void_p()
         self.h_voc = self.h  # the handle the vocoder entries are called on (its own when the precisions differ)
         with torch.cuda.device(self.device):
@@ -55,7 +57,7 @@ class NativePipeline:
             self._upload_acoustic(ac)
             if split:
                 self.h_voc = C.c_void_p()
-                cfg_v = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), kind_code, compute_v, 0, post_b)
+                cfg_v = capi.TtsConfig(int(self.multilingual), int(self.multispeaker), kind_code, compute_v, stb, post_b)
                 capi.check(self.lib.tts_create(C.byref(cfg_v), C.byref(self.h_voc)), "tts_create (vocoder)")
             else:
                 self.h_voc = self.h
