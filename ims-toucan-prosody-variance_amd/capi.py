@@ -98,6 +98,7 @@ IO_SPLIT_K = 16  # tts_conv1d, fp32: the caller accepts the split-K form on smal
 PROTOTYPES = {
     "tts_last_error": (C.c_char_p, []),
     "tts_abi_version": (C.c_int, []),
+    "tts_diag_queue_nonzero": (C.c_int, []),
     "tts_conv1d_tile_rows": (C.c_int, [_i, _i]),
     "tts_conv1d_n_tile": (C.c_int, [_i, _i]),
     "tts_conv1d_small_tile_rows": (C.c_int, [_i, _i, _i]),
@@ -155,7 +156,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 12  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 13  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

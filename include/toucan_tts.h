@@ -385,9 +385,13 @@ int tts_synthesize_batch(TtsHandle* h, const float* text, const float* utt_emb, 
                          int32_t* frame_counts /*host*/, float* wav, int64_t wav_capacity, int64_t* wav_needed /*host*/, tts_stream_t stream);
 
 const char* tts_last_error(void);
+/* Self-check: synchronises the device and returns how many words of the residual-step work queues are not zero (every
+ * tts_resblock_step launch draws its tiles from one 16-word slot and must leave it zero again).  0 = clean; negative = HIP error.
+ * The test suite calls it after every GPU test. */
+int tts_diag_queue_nonzero(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 12
+#define TTS_ABI_VERSION 13
 int tts_abi_version(void);
 
 #ifdef __cplusplus

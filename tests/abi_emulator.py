@@ -125,6 +125,9 @@ class Emulator:
     def tts_abi_version(self):
         return capi.ABI_VERSION
 
+    def tts_diag_queue_nonzero(self):
+        return 0  # (the emulator has no work queues)
+
     def tts_conv1d_tile_rows(self, cout, mode):
         return self._reallib().tts_conv1d_tile_rows(cout, mode)
 

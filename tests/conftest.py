@@ -27,7 +27,5 @@ def _work_queues_left_clean(request):
     if not torch.cuda.is_available():
         return
     from ims_toucan_prosody_variance_amd import capi
-    fn = getattr(capi.lib(), "tts_diag_queue_nonzero", None)
-    if fn is not None:
-        dirty = fn()
-        assert dirty == 0, f"{dirty} non-zero words left in the residual-step work queues (negative: HIP error)"
+    dirty = capi.lib().tts_diag_queue_nonzero()
+    assert dirty == 0, f"{dirty} non-zero words left in the residual-step work queues (negative: HIP error)"
