@@ -19,6 +19,8 @@
 //     register r of a lane is key (r&3)+8(r>>2)+4hi, so "k-pair r" of the product pairs keys (base_r, base_r+4) and the
 //     A operand V^T is simply read from LDS with that key order.  No transpose, no conversion.
 //   * keys beyond the utterance get -inf; queries beyond it are computed and discarded.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace tts {
@@ -27,23 +29,30 @@ constexpr int AM_DK = 48, AM_QT = 128, AM_KT = 32, AM_PW = AM_QT + AM_KT - 1;  /
 constexpr int AM_PITCH = AM_DK + 1;                                           // odd pitch: column reads hit distinct banks
 constexpr int AM_GP = 33;                                                     // scratch pitch
 
+// SPLIT (grids of a few workgroups - batch 1): the four wavefronts of a workgroup share ONE block of 32 queries and split the keys
+// (wavefront w takes keys j0 + 32 w .. of every 128-key step), then their running (max, sum, O^T) meet in LDS and wavefront 0
+// writes the block: 4x the workgroups, a quarter of the dependent fp32 MFMA chain per wavefront.  Same staging, same products.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                                     const float* __restrict__ ptab, int pmax,
                                                                     const float* __restrict__ bias_u, const float* __restrict__ bias_v,
                                                                     float* __restrict__ ctx, int ld_ctx, int heads,
                                                                     const TtsTile* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) float am_lds[];
-  float* Ks = am_lds;                              // [KT][PITCH]
-  float* Vs = Ks + AM_KT * AM_PITCH;               // [KT][PITCH]
-  float* Ps = Vs + AM_KT * AM_PITCH;               // [PW+1][PITCH]
+  constexpr int KROWS = SPLIT ? 4 * AM_KT : AM_KT;  // keys staged per step
+  float* Ks = am_lds;                              // [KROWS][PITCH]
+  float* Vs = Ks + KROWS * AM_PITCH;               // [KROWS][PITCH]
+  float* Ps = Vs + KROWS * AM_PITCH;               // [PW+1][PITCH]
   float* Gs = Ps + (AM_PW + 1) * AM_PITCH;         // [4][64*GP] per-wave scratch
 
-  const TtsTile t = tiles[blockIdx.x];
+  const TtsTile t = tiles[SPLIT ? blockIdx.x >> 2 : blockIdx.x];
   const int h = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
   const int n = t.seq_end - t.seq_begin;
-  const int qbase = t.row0 - t.seq_begin;     // local index of the workgroup's first query
-  const int qw = qbase + wave * 32;           // local index of this wave's first query
+  const int qbase = t.row0 - t.seq_begin + (SPLIT ? 32 * (int)(blockIdx.x & 3) : 0);  // local index of the workgroup's first query
+  if (SPLIT && qbase >= n) return;            // (the whole workgroup: a query block behind the utterance)
+  const int qw = SPLIT ? qbase : qbase + wave * 32;  // local index of this wave's first query
+  const int kw = SPLIT ? wave * 32 : 0;       // this wave's first key row of a staged step
   const int qi = qw + li;                     // this lane's query (local)
   const int qrow = t.seq_begin + (qi < n ? qi : n - 1);
   const int hd = heads * AM_DK;
@@ -67,10 +76,10 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
   float m_run = -INFINITY, l_run = 0.f;
   const float scale = 1.0f / sqrtf((float)AM_DK);
 
-  for (int j0 = 0; j0 < n; j0 += AM_KT) {
+  for (int j0 = 0; j0 < n; j0 += KROWS) {
     __syncthreads();
-    // ---- stage K, V (keys j0..j0+31) and the table window (relative positions qbase-j0-31 .. qbase-j0+127) ----
-    for (int e = tid; e < AM_KT * (AM_DK / 4); e += 256) {
+    // ---- stage K, V (keys j0..j0+KROWS-1) and the table window (159 relative positions: 128 queries x 32 keys, or 32 x 128) ----
+    for (int e = tid; e < KROWS * (AM_DK / 4); e += 256) {
       const int jj = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
       const int jr = j0 + jj < n ? j0 + jj : n - 1;
       const float* base = qkv + (size_t)(t.seq_begin + jr) * ld_qkv + h * AM_DK + c4;
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
       kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
       vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
     }
-    const int p0 = qbase - j0 - (AM_KT - 1);
+    const int p0 = qbase - j0 - (KROWS - 1);
     for (int e = tid; e < (AM_PW + 1) * (AM_DK / 4); e += 256) {
       const int w = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
       int pr = pmax - 1 + p0 + w;
@@ -91,19 +100,21 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
       pd[0] = pv.x; pd[1] = pv.y; pd[2] = pv.z; pd[3] = pv.w;
     }
     __syncthreads();
+    if (SPLIT && j0 + kw >= n) continue;  // (this wavefront's 32 keys lie behind the utterance; the barriers above are met by all)
 
     // ---- S^T = K (Q+u)^T : rows = keys, column = query ----
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < AM_DK / 2; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[li * AM_PITCH + 2 * kk + hi], qu[kk], s, 0, 0, 0);
+    for (int kk = 0; kk < AM_DK / 2; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(kw + li) * AM_PITCH + 2 * kk + hi], qu[kk], s, 0, 0, 0);
 
     // ---- G^T = Pwin (Q+v)^T for this wave's 63-row sub-window (rows w = wave*32 + 0..63 of the staged window) ----
     f32x16 g0, g1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
-    const float* pw = Ps + (wave * 32) * AM_PITCH;
+    // (SPLIT: query i = qbase + li, key j = j0 + 32 wave + jj -> window row (i - j) - p0 = (96 - 32 wave) + (li - jj + 31))
+    const float* pw = Ps + (SPLIT ? 96 - 32 * wave : wave * 32) * AM_PITCH;
 #pragma unroll
     for (int kk = 0; kk < AM_DK / 2; ++kk) {
       g0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pw[li * AM_PITCH + 2 * kk + hi], qv[kk], g0, 0, 0, 0);
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
       // relative position i - j = (qw + li) - (j0 + jj); sub-window row w = (i - j) - (qw - j0 - 31) = li - jj + 31
       const float bd = gs[(li - jj + 31) * AM_GP + li];
       float sc = (s[r] + bd) * scale;
-      sc = (j0 + jj < n) ? sc : -INFINITY;
+      sc = (j0 + kw + jj < n) ? sc : -INFINITY;
       s[r] = sc;
       m_tile = fmaxf(m_tile, sc);
     }
@@ -149,13 +160,46 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float a0 = Vs[key * AM_PITCH + li];
-      const float a1 = Vs[key * AM_PITCH + (li < 16 ? 32 + li : 47)];  // d = 32..47 valid; rows 48..63 of O^T are discarded
+      const float a0 = Vs[(kw + key) * AM_PITCH + li];
+      const float a1 = Vs[(kw + key) * AM_PITCH + (li < 16 ? 32 + li : 47)];  // d = 32..47 valid; rows 48..63 of O^T are discarded
       o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
     }
   }
 
+  if constexpr (SPLIT) {
+    // ---- the four partial results of the query block meet in LDS (over K / V, which nobody reads any more) ----
+    __syncthreads();
+    float* mg = am_lds;  // [4 waves][34][64 lanes]: O^T registers 0..31, running max, running sum
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      mg[(wave * 34 + r) * 64 + lane] = o0[r];
+      mg[(wave * 34 + 16 + r) * 64 + lane] = o1[r];
+    }
+    mg[(wave * 34 + 32) * 64 + lane] = m_run;
+    mg[(wave * 34 + 33) * 64 + lane] = l_run;
+    __syncthreads();
+    if (wave != 0) return;
+    float mw[4], m_all = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      mw[w] = mg[(w * 34 + 32) * 64 + lane];
+      m_all = fmaxf(m_all, mw[w]);  // finite: wavefront 0 saw key 0
+    }
+    l_run = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = __expf(mw[w] - m_all);  // 0 for a wavefront that saw no key (max -inf, sum 0)
+      l_run += mg[(w * 34 + 33) * 64 + lane] * f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] += mg[(w * 34 + r) * 64 + lane] * f;
+        o1[r] += mg[(w * 34 + 16 + r) * 64 + lane] * f;
+      }
+    }
+  }
   // ---- ctx[i][h*dk + d] = O^T[d][i] / l : transpose through the scratch so that every row is written contiguously ----
   const float inv = 1.0f / l_run;
 #pragma unroll
@@ -373,11 +417,21 @@ int relpos_attention_mfma(const float* qkv, int ld_qkv, const float* ptab, int p
   TTS_CHECK_ARG((ld_qkv & 3) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ptab & 15) == 0, "relpos_attention: alignment");
   TTS_CHECK_ARG((ld_ctx & 3) == 0 && ((uintptr_t)ctx & 15) == 0, "relpos_attention: ctx alignment");
   if (n_tiles == 0) return TTS_OK;
-  const size_t lds = (size_t)(2 * AM_KT * AM_PITCH + (AM_PW + 1) * AM_PITCH + 4 * 64 * AM_GP) * sizeof(float);
-  static unsigned long long lds_raised = 0;  // per device (common.h)
-  if (lds > 64 * 1024) (void)raise_lds_limit(reinterpret_cast<const void*>(relpos_attention_mfma_kernel), lds_raised);
-  hipLaunchKernelGGL(relpos_attention_mfma_kernel, dim3(n_tiles, heads), dim3(256), lds, st, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx,
-                     ld_ctx, heads, tiles);
+  // batch 1: 4 (encoder) or 20 (decoder, 640 frames) workgroups with a dependent chain of 104 fp32 MFMAs per 32 keys each -
+  // the key-split form puts 4x the workgroups on the chip (its result differs from the plain form's at rounding-order level)
+  const bool split = (long long)n_tiles * heads <= 64 && std::getenv("TOUCAN_NO_ATTENTION_SPLIT") == nullptr;
+  const size_t lds = (size_t)(2 * (split ? 4 : 1) * AM_KT * AM_PITCH + (AM_PW + 1) * AM_PITCH + 4 * 64 * AM_GP) * sizeof(float);
+  if (split) {
+    static unsigned long long lds_raised = 0;  // per device (common.h)
+    if (lds > 64 * 1024) (void)raise_lds_limit(reinterpret_cast<const void*>(relpos_attention_mfma_kernel<true>), lds_raised);
+    hipLaunchKernelGGL(relpos_attention_mfma_kernel<true>, dim3(4 * n_tiles, heads), dim3(256), lds, st, qkv, ld_qkv, ptab, pmax, bias_u, bias_v,
+                       ctx, ld_ctx, heads, tiles);
+  } else {
+    static unsigned long long lds_raised = 0;
+    if (lds > 64 * 1024) (void)raise_lds_limit(reinterpret_cast<const void*>(relpos_attention_mfma_kernel<false>), lds_raised);
+    hipLaunchKernelGGL(relpos_attention_mfma_kernel<false>, dim3(n_tiles, heads), dim3(256), lds, st, qkv, ld_qkv, ptab, pmax, bias_u, bias_v,
+                       ctx, ld_ctx, heads, tiles);
+  }
   return launch_status("relpos_attention(mfma)");
 }
 

@@ -319,6 +319,30 @@ def test_relpos_attention(gpu, cpu, lengths, tile_rows):
     close(*both(gpu, cpu, run), tol=5e-5)
 
 
+@pytest.mark.parametrize("lengths", [[7], [640], [333, 129], [160, 33, 1]])
+def test_relpos_attention_key_split_form(gpu, cpu, lengths, monkeypatch):
+    """fp32 attention on grids of a few workgroups: the four wavefronts of a workgroup split the keys of one 32-query block and merge
+    their running (max, sum, output) in LDS.  Against the emulator, and against the plain form (TOUCAN_NO_ATTENTION_SPLIT): rounding
+    order only - and really another kernel (the last bits differ)."""
+    pmax = 700
+
+    def run(ops, to):
+        rag = Ragged(lengths, ops.device, align=2)
+        qkv = to(rnd(rag.total_rows, 576, seed=1, scale=0.7))
+        ptab = to(rnd(2 * pmax - 1, 192, seed=2, scale=0.5))
+        ctx = to(torch.zeros(rag.total_rows, 192))
+        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, 128)
+    g, c = both(gpu, cpu, run)
+    monkeypatch.setenv("TOUCAN_NO_ATTENTION_SPLIT", "1")
+    plain = run(gpu, lambda t: t.to("cuda:0").contiguous())
+    close(g, c, tol=5e-5)
+    close(g, plain, tol=1e-5)
+    if max(lengths) > 32:  # (with a single 32-key step the merge is exact: wavefront 0 holds everything)
+        assert not torch.equal(g, plain), "the key-split form did not run"
+    else:
+        assert torch.equal(g, plain)
+
+
 @pytest.mark.parametrize("lengths", [[640, 37, 128, 1], [129], [700]])
 def test_relpos_attention_f16(gpu, cpu, lengths):
     """tts_relpos_attention_f16 (the three contractions on the fp16 matrix cores) against the emulator with the same rounding points,
