@@ -79,6 +79,21 @@ def main():
     print(json.dumps({"config": "configs[0]-like: one 20-phoneme utterance, predicted durations, acoustic + Avocodo fp32, end to end",
                       "graphs": args.graphs, "sequencer": tag, "ms": 1e3 * t, "audio_s": wav.numel() / 24000.0, "rtf": t / (wav.numel() / 24000.0)}))
 
+    if use_native:
+        # one 128-phoneme sentence (10.2 s of audio) end to end with BigVGAN, the way read_to_file meets a single sentence: the exact
+        # configuration (fp32 everywhere) and the mixed one (fp32 acoustic model = the same mel bit for bit, fp16 vocoder)
+        L = 128
+        text = [torch.from_numpy(syn.utterance_features(0, L, word_boundaries=False)).to(dev)]
+        emb = torch.from_numpy(syn.utterance_embedding(0))[None].to(dev)
+        dur = [torch.full((L,), 5, dtype=torch.int32, device=dev)]
+        z = [torch.from_numpy(syn.postflow_noise(0, 5 * L)).to(dev)]
+        for name, vp in (("fp32", None), ("mixed (fp32 acoustic + fp16 vocoder)", "f16")):
+            p2 = native.NativePipeline(fw.acoustic_state_dict(), fw.bigvgan_state_dict(), "bigvgan", dev, precision="f32", vocoder_precision=vp)
+            run = lambda: p2.forward(text, emb, [syn.LANG_EN], durations=dur, z_noise=z)
+            t = timeit(run, args.reps)
+            print(json.dumps({"config": f"one 128-phoneme sentence (640 frames, 10.24 s of audio), acoustic + BigVGAN, {name}, end to end",
+                              "sequencer": tag, "ms": 1e3 * t, "rtf": t / 10.24}))
+
 
 if __name__ == "__main__":
     main()
