@@ -933,14 +933,15 @@ static bool splitk_ok(const TtsConvDesc& d, int cols) {
   if (d.compute != 0 || !(d.io_flags & TTS_IO_SPLIT_K) || (d.io_flags & TTS_IO_X_BF16) || d.pre_act == TTS_PRE_SNAKE) return false;
   if ((d.cin & 7) != 0 || d.cin < 32 || (d.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0 || (cols & 31) != 0) return false;
   static const int min_depth = std::getenv("TOUCAN_SPLIT_K_MIN") ? std::atoi(std::getenv("TOUCAN_SPLIT_K_MIN")) : 64;  // (A/B runs)
-  if ((long long)d.taps * d.cin < min_depth || (long long)d.n_tiles * (d.tile_rows / 64) * ((cols + 63) / 64) > 128) return false;
+  static const int max_grid = std::getenv("TOUCAN_SPLIT_K_GRID") ? std::atoi(std::getenv("TOUCAN_SPLIT_K_GRID")) : 128;  // (A/B runs)
+  if ((long long)d.taps * d.cin < min_depth || (long long)d.n_tiles * (d.tile_rows / 64) * ((cols + 63) / 64) > max_grid) return false;
   return std::getenv("TOUCAN_NO_SPLIT_K") == nullptr;  // escape hatch for A/B measurements
 }
 
 static int launch_splitk(const TtsConvDesc& d, int cols, hipStream_t st) {
   const bool dual = d.mode != TTS_MODE_LINEAR;
   // 16 x 16 tiles while the 32 x 32 grid is at most 128 workgroups (and the channels come in whole groups of 16)
-  if ((d.cin & 15) == 0 && d.cin >= 64 && (long long)d.n_tiles * (d.tile_rows / 32) * (cols / 32) <= 128 && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
+  if ((d.cin & 15) == 0 && d.cin >= 64 && (long long)d.n_tiles * (d.tile_rows / 32) * (cols / 32) <= (std::getenv("TOUCAN_SPLIT_K16_GRID") ? std::atoi(std::getenv("TOUCAN_SPLIT_K16_GRID")) : 128) && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
     dim3 grid(d.n_tiles * (d.tile_rows / 16), cols / 16), block(256);
     if (dual) hipLaunchKernelGGL((conv_splitk_f32_kernel<true, true>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((conv_splitk_f32_kernel<false, true>), grid, block, 0, st, d);
