@@ -72,7 +72,7 @@ def relaunch_distributed(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def cpu_baseline(phones, frames_per_phone, vocoder):
+def cpu_baseline(phones, frames_per_phone, vocoder, scales=None):
     """The CPU oracle (kind 'port') on a bounded sample: ONE utterance of the same workload, processed the way the
     reference's read_to_file does (one utterance at a time), all host cores."""
     import numpy as np
@@ -96,7 +96,7 @@ def cpu_baseline(phones, frames_per_phone, vocoder):
     times_a, times_v = [], []
     for it in range(3):
         t0 = time.perf_counter()
-        o = oa(feats, emb, syn.LANG_EN, z_noise=z, durations=dur)
+        o = oa(feats, emb, syn.LANG_EN, z_noise=z, durations=dur, **(scales or {}))
         t1 = time.perf_counter()
         w = ov(o["mel"].t().contiguous())
         t2 = time.perf_counter()
@@ -109,15 +109,15 @@ def cpu_baseline(phones, frames_per_phone, vocoder):
                 sample=f"1 utterance x {phones} phonemes ({frames} frames, {w.numel() / 24000.0:.2f} s audio), "
                        f"acoustic + {vocoder}, fp32, median of 2 after 1 warm-up",
                 acoustic_mel_frames_per_s=frames / ta, vocoder_rtf=tv / (w.numel() / 24000.0),
-                e2e_rtf=(ta + tv) / (w.numel() / 24000.0))
+                e2e_rtf=(ta + tv) / (w.numel() / 24000.0)), (o["mel"], w)
 
 
-def committed_counters(kernel):
+def committed_counters(kernel, algorithmic_bytes=None):
     """HBM bytes per launch and VALU lane-operations per element of `kernel` from this round's committed rocprofv3 PMC passes
     (separate --pmc runs over tools/microbench_resblock.py at the bench's shapes; FETCH_SIZE doubled per MI355X_MICROARCH.md).
     Counter passes cannot share a process with the timed region, so these are read from profiles/; the file is named in the
     line.  (None, None, None) when no pass covers the kernel."""
-    for tag in ("r02", "r01_v18", "r01"):
+    for tag in ("r03", "r02", "r01_v18", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_resblock_traffic.json")
         if not os.path.exists(path):
             continue
@@ -125,6 +125,11 @@ def committed_counters(kernel):
             rows = [r for r in json.load(f)["launches"] if r["kernel"] == kernel and r["act"] == "snake"]
         if not rows:
             continue
+        if algorithmic_bytes is not None:
+            # the counter pass ran the micro-benchmark, not this process: its launch must be the bench's launch (same rows x channels
+            # x 16-bit read + write), or the traffic figure would describe another shape
+            assert all(abs(r["algorithmic_bytes"] - algorithmic_bytes) <= 1e-6 * algorithmic_bytes for r in rows), \
+                f"{path}: counter pass shape ({rows[0]['algorithmic_bytes']} B per launch) is not the bench's launch ({algorithmic_bytes} B)"
         traffic = sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
         valu = None
         sq = os.path.join(ROOT, "profiles", f"{tag}_pmc_resblock_SQ_summary.json")
@@ -134,6 +139,90 @@ def committed_counters(kernel):
             valu = sum(v) / len(v) if v else None
         return traffic, valu, os.path.relpath(path, ROOT)
     return None, None, None
+
+
+class TwoStreamRunner:
+    """bench.py's default step on one GPU: the acoustic model of step k+1 is enqueued on one HIP stream beside the vocoder of step k on
+    another (the mel crosses in forward()'s own copy behind an event; the handle keeps the acoustic stages' arenas and the vocoder's
+    apart).  tests/test_gpu_product_path.py drives this very class at full size against the Python sequencer, bit for bit."""
+
+    def __init__(self, pipe, packed, z_sq, scales, dev, priority=-1):
+        import torch
+        self.torch, self.pipe, self.packed, self.z_sq, self.scales = torch, pipe, packed, z_sq, dict(scales)
+        # the acoustic stream has the higher priority: its short kernels take the CUs a vocoder launch frees in its tail before
+        # the next vocoder launch's persistent workgroups do (42.0 vs 42.25 ms measured; TOUCAN_BENCH_AC_PRIORITY=0 for the A/B run)
+        self.s_ac, self.s_voc = torch.cuda.Stream(dev, priority=priority), torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)  # the resident inputs were written on the caller's stream
+        self.s_ac.wait_stream(cur)
+        self.s_voc.wait_stream(cur)
+
+    def step(self, ev=None, after_vocoder=None):
+        """ev: four timing events (acoustic begin / end, vocoder end / begin) recorded on the stage's own stream; after_vocoder(wav):
+        called inside the vocoder stream's context (the multi-GPU exchange step)."""
+        torch, pipe = self.torch, self.pipe
+        with torch.cuda.stream(self.s_ac):
+            if ev:
+                ev[0].record(self.s_ac)
+            out = pipe.forward(None, None, packed=self.packed, z_sq=self.z_sq, vocode=False, **self.scales)
+            if ev:
+                ev[1].record(self.s_ac)
+            done = torch.cuda.Event()
+            done.record(self.s_ac)
+        with torch.cuda.stream(self.s_voc):
+            self.s_voc.wait_event(done)
+            out["mel_packed"].record_stream(self.s_voc)
+            if ev:
+                ev[3].record(self.s_voc)
+            wav, _ = pipe.vocode(out["mel_packed"], out["rag_mel"])
+            if ev:
+                ev[2].record(self.s_voc)
+            if after_vocoder is not None:
+                after_vocoder(wav)
+        return out, wav
+
+
+def verify_against_single_run(pipe, out, wav, packed, z_sq, scales, B, oracle=None):
+    """The `verify` object of the line: utterance 0 of a finished step (mel and waveform as the timed path produced them) against
+    the SAME utterance run alone (B = 1) through the same handle - computed after the timed region.  16-bit configurations:
+    bit-identical by construction (an utterance's arithmetic never depends on the batch); fp32: the frame stages may take the
+    split forms on the small grid of a B = 1 run, so the difference is rounding order (reported).  oracle: (mel, wav) of the CPU
+    oracle on the same utterance - the checker, run by the cpu_baseline leg - adds the error against it."""
+    import torch
+    from ims_toucan_prosody_variance_amd.ragged import Ragged
+    L0 = packed["Ls"][0]
+    cut = lambda t, n: None if t is None else t[:n].contiguous()
+    one = dict(Ls=[L0], text=cut(packed["text"], L0), emb=cut(packed["emb"], 1), lang=cut(packed["lang"], 1), gp=cut(packed["gp"], L0),
+               ge=cut(packed["ge"], L0), gd=cut(packed["gd"], L0))
+    T0 = int(out["rag_frame"].lengths[0])
+    rs = Ragged([T0], pipe.device, align=2).halved()
+    o1 = pipe.forward(None, None, packed=one, z_sq=z_sq[: rs.total_rows].contiguous(), vocode=False, **scales)
+    w1, _ = pipe.vocode(o1["mel_packed"], o1["rag_mel"])
+    torch.cuda.synchronize()
+    n = int(out["rag_mel"].lengths[0])
+    b0 = int(out["rag_mel"].begins[0])
+    mel_b, mel_1 = out["mel_packed"][b0:b0 + n], o1["mel_packed"][:n]
+    wav_b, wav_1 = wav[384 * b0:384 * (b0 + n)], w1[: 384 * n]
+    v = {"utterance": 0, "frames": n, "against": f"the same utterance run alone (B = 1) vs in the batch of {B}",
+         "finite": bool(torch.isfinite(mel_b).all() and torch.isfinite(wav_b).all()),
+         "mel_bit_identical": bool(torch.equal(mel_b, mel_1)), "wav_bit_identical": bool(torch.equal(wav_b, wav_1)),
+         "mel_max_abs_diff": float((mel_b - mel_1).abs().max()), "wav_max_abs_diff": float((wav_b - wav_1).abs().max())}
+    if oracle is not None:
+        mel_o, wav_o = (t.to(mel_b.device) for t in oracle)
+        if tuple(mel_o.shape) == tuple(mel_b.shape):
+            v["vs_cpu_oracle_fp32"] = {"mel_mean_abs_err": float((mel_b - mel_o).abs().mean()), "mel_max_abs_err": float((mel_b - mel_o).abs().max()),
+                                       "mel_mean_abs": float(mel_o.abs().mean()), "wav_mean_abs_err": float((wav_b - wav_o).abs().mean()),
+                                       "wav_max_abs_err": float((wav_b - wav_o).abs().max()), "wav_mean_abs": float(wav_o.abs().mean())}
+    return v
+
+
+def algorithmic_flops_per_utterance(L, T, vocoder):
+    """FLOPs (2 x MAC) of one utterance of L phonemes -> T frames.  Conformer block of length N:
+    3 022 848 N + 1 536 N^2 + 384 K N (K = 7 encoder / 31 decoder); predictors 0.66 G at L = 128; feat_out + PostNet 1.54 G and
+    PostFlow 27.63 G at T = 640 (linear in T); vocoder 677.15 (BigVGAN) / 648.24 (Avocodo) MFLOP per mel frame."""
+    block = lambda n, k: 3022848.0 * n + 1536.0 * n * n + 384.0 * k * n
+    acoustic = 6 * block(L, 7) + 6 * block(T, 31) + 0.66e9 * L / 128 + (1.54e9 + 27.63e9) * T / 640
+    voc = (677.15e6 if vocoder == "bigvgan" else 648.24e6) * (T - T % 2)
+    return acoustic, voc
 
 
 def log(msg):
@@ -199,7 +288,6 @@ def main():
     gathered = torch.empty(world * B * T * 384, device="cpu" if rehearsal else dev) if world > 1 else None
     gathered2 = [gathered, torch.empty_like(gathered)] if world > 1 else None  # (two-stream form: the exchange of step k runs beside step k+1)
     gather_no = [0]
-    comm_stream_ok = [True]
 
     packed = z_sq = None
     if use_native:  # the stage API's input format (packed along the phoneme axis): resident in HBM before the timed region
@@ -207,55 +295,30 @@ def main():
         z_sq = pipe.squeeze_noise(zs, [T] * B)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     overlap = use_native and not args.no_overlap
-    s_ac = s_voc = s_comm = None
+    runner = s_comm = None
     if overlap:
         s_comm = torch.cuda.Stream(dev) if world > 1 else None
-        # the acoustic stream has the higher priority: its short kernels take the CUs a vocoder launch frees in its tail before
-        # the next vocoder launch's persistent workgroups do (42.0 vs 42.25 ms measured; TOUCAN_BENCH_AC_PRIORITY=0 for the A/B run)
-        s_ac, s_voc = torch.cuda.Stream(dev, priority=int(os.environ.get("TOUCAN_BENCH_AC_PRIORITY", "-1"))), torch.cuda.Stream(dev)
+        runner = TwoStreamRunner(pipe, packed, z_sq, scales, dev, priority=int(os.environ.get("TOUCAN_BENCH_AC_PRIORITY", "-1")))
+
+    def exchange(wav):
+        """The exchange step on its own stream: the vocoder of step k+1 does not wait for the waveforms of step k to cross xGMI
+        (31.5 MB per rank and step); all of it is inside the timed region (the final device synchronise).  A failing collective
+        ends the run (no retry on another stream: a broken communicator must not hide behind a slower path)."""
+        block = wav[: B * T * 384].contiguous()
+        dst = gathered2[gather_no[0] & 1]
+        gather_no[0] += 1
+        if rehearsal:
+            dist.all_gather_into_tensor(dst, block.cpu())
+            return
+        voc_done = torch.cuda.Event()
+        voc_done.record(runner.s_voc)
+        with torch.cuda.stream(s_comm):
+            s_comm.wait_event(voc_done)
+            block.record_stream(s_comm)
+            dist.all_gather_into_tensor(dst, block)
 
     def step_overlapped(record=False):
-        """Two streams: the acoustic model of this step is enqueued on s_ac, its vocoder on s_voc behind an event; the next
-        step's acoustic model does not wait for this step's vocoder.  The mel handed over is forward()'s own copy."""
-        with torch.cuda.stream(s_ac):
-            if record:
-                ev[0].record(s_ac)
-            out = pipe.forward(None, None, packed=packed, z_sq=z_sq, vocode=False, **scales)
-            if record:
-                ev[1].record(s_ac)
-            done = torch.cuda.Event()
-            done.record(s_ac)
-        with torch.cuda.stream(s_voc):
-            s_voc.wait_event(done)
-            out["mel_packed"].record_stream(s_voc)
-            if record:
-                ev[3].record(s_voc)
-            wav, _ = pipe.vocode(out["mel_packed"], out["rag_mel"])
-            if record:
-                ev[2].record(s_voc)
-            if world > 1:
-                # the exchange step on its own stream: the vocoder of step k+1 does not wait for the waveforms of step k to cross
-                # xGMI (31.5 MB per rank and step); all of it is inside the timed region (the final device synchronise)
-                block = wav[: B * T * 384].contiguous()
-                voc_done = torch.cuda.Event()
-                voc_done.record(s_voc)
-                dst = gathered2[gather_no[0] & 1]
-                gather_no[0] += 1
-                if rehearsal:
-                    dist.all_gather_into_tensor(dst, block.cpu())
-                elif comm_stream_ok[0]:
-                    try:
-                        with torch.cuda.stream(s_comm):
-                            s_comm.wait_event(voc_done)
-                            block.record_stream(s_comm)
-                            dist.all_gather_into_tensor(dst, block)
-                    except Exception as e:  # (never seen; the plain form below is the one round 1 measured)
-                        log(f"exchange on its own stream failed ({e!r}): falling back to the vocoder stream")
-                        comm_stream_ok[0] = False
-                        dist.all_gather_into_tensor(dst, block)
-                else:
-                    dist.all_gather_into_tensor(dst, block)
-        return out, wav
+        return runner.step(ev if record else None, exchange if world > 1 else None)
 
     def step(record=False, tx=texts, em=embs, zz=zs, resident=True):
         if overlap and resident:
@@ -325,6 +388,9 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     t_ac = t_voc = 0.0
+    step_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # completion of every timed step, on the stream that ends it
+    end_stream = lambda: runner.s_voc if overlap else torch.cuda.current_stream(dev)
+    step_done[0].record(end_stream())
     for it in range(args.steps):
         log(f"timed step {it}")
         if overlap:  # no host wait between steps: the streams overlap consecutive steps; stage times from the last step only
@@ -334,9 +400,9 @@ def main():
             ev[2].synchronize()
             t_ac += ev[0].elapsed_time(ev[1]) * 1e-3
             t_voc += ev[1].elapsed_time(ev[2]) * 1e-3
+        step_done[it + 1].record(end_stream())
     torch.cuda.synchronize()
-    if overlap:  # (the two stages of one step, each running beside the other stage of a neighbouring step)
-        t_ac = ev[0].elapsed_time(ev[1]) * 1e-3 * args.steps
+    if overlap:  # (the vocoder of one step, running beside the acoustic model of the next)
         t_voc = ev[3].elapsed_time(ev[2]) * 1e-3 * args.steps
     if world > 1:
         dist.barrier()
@@ -357,6 +423,27 @@ def main():
 
     frames_out = int(sum(m.shape[0] for m in out["mel"]))
     audio_s = frames_out * 384 / 24000.0
+    # HIP-event time between the completions of consecutive timed steps (event timing, median beside the mean)
+    step_ms = sorted(step_done[i].elapsed_time(step_done[i + 1]) for i in range(args.steps))
+    step_ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+
+    # ---- after the timed region: the acoustic model's own rate (one stream, nothing beside it) and the parity check of the
+    #      timed path's output ----
+    acoustic_alone_ms = None
+    last_out, last_wav = out, wav
+    if use_native:
+        torch.cuda.synchronize()
+        pe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        n_probe = 3
+        pipe.forward(None, None, packed=packed, z_sq=z_sq, vocode=False, **scales)
+        pe[0].record()
+        for _ in range(n_probe):
+            pipe.forward(None, None, packed=packed, z_sq=z_sq, vocode=False, **scales)
+        pe[1].record()
+        torch.cuda.synchronize()
+        acoustic_alone_ms = pe[0].elapsed_time(pe[1]) / n_probe
+        if overlap:
+            t_ac = acoustic_alone_ms * 1e-3 * args.steps
 
     # ---- PCIe-inclusive rate (SURVEY.md 8(d) protocol): phoneme tensors / embeddings / noise from pinned host memory in,
     #      waveforms to pinned host memory out, every step; reported beside `value` ----
@@ -370,7 +457,7 @@ def main():
             tx = [t.to(dev, non_blocking=True) for t in host_texts]
             em = host_embs.to(dev, non_blocking=True)
             zz = [z.to(dev, non_blocking=True) for z in host_zs]
-            _, w = step(tx=tx, em=em, zz=zz, resident=False)
+            _, w = step(tx=tx, em=em, zz=zz, resident=False)  # (one stream: host tensors -> acoustic model -> vocoder -> host)
             host_wav.copy_(w, non_blocking=True)
         torch.cuda.synchronize()
         tp = (time.perf_counter() - tp0) / n_pcie
@@ -384,7 +471,7 @@ def main():
             dom = dom_summary
             is16 = ("bf16" in dominant or "f16" in dominant or "resblock" in dominant) and "f32" not in dominant
             peak = PEAK_16BIT_TFLOPS if is16 else PEAK_F32_TFLOPS
-            traffic, valu_per_elem, src = committed_counters(dominant)
+            traffic, valu_per_elem, src = committed_counters(dominant, dom["bytes_per_launch"])
             mfma_frac = dom["tflops"] / peak
             gbs = dom["bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9
             hbm_frac = gbs / PEAK_HBM_GBS
@@ -405,6 +492,13 @@ def main():
                     "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                     "avg_launch_us": dom["avg_us"], "launches_per_step": dom["launches"] / args.steps,
                     "flops_per_launch": dom["flops_per_launch"], "share_of_step": dom["total_ms"] / (1e3 * elapsed)}
+        fa, fv = algorithmic_flops_per_utterance(L, frames_out // B, args.vocoder)
+        step_flops = B * (fa + fv)
+        step_peak = PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_16BIT_TFLOPS
+        step_roof = {"flops_per_step": step_flops, "acoustic_flops_per_utterance": fa, "vocoder_flops_per_utterance": fv,
+                     "achieved_tflops": step_flops / (elapsed / args.steps) / 1e12, "peak_tflops": step_peak,
+                     "frac": step_flops / (elapsed / args.steps) / 1e12 / step_peak,
+                     "note": "algorithmic FLOPs of the whole step (SURVEY.md 8(d)) / step time / dense MFMA peak of the vocoder's dtype"}
         cfg_name = {"bf16": "configs[2]", "fp16": "configs[4] (per-GPU shard)", "fp32": "configs[2] shape in fp32",
                     "mixed": "configs[2] shape, acoustic model in fp32 (exact mel parity) + fp16 vocoder"}[args.dtype]
         line = {
@@ -424,8 +518,13 @@ def main():
                        "hip_graphs": bool(args.graphs),
                        "sequencer": "native stage API (csrc/pipeline.hip)" if use_native else "python (engine.py)",
                        "streams": "2 HIP streams: acoustic model of step k+1 beside the vocoder of step k" if overlap else "1 HIP stream"},
+            # the acoustic model alone on the GPU (one stream, measured after the timed region); in the two-stream form the vocoder's
+            # time is that of the last step's vocoder running beside the next step's acoustic model
             "acoustic_mel_frames_per_s": world * frames_out * args.steps / t_ac,
+            "acoustic_ms_alone": acoustic_alone_ms,
             "vocoder_rtf": t_voc / (args.steps * audio_s),
+            "ms_per_step_median_events": step_ms_median, "ms_per_step_min_max_events": [step_ms[0], step_ms[-1]],
+            "step_roofline": step_roof,
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),
             "abi_calls_per_step": abi_calls,
             "pcie_inclusive": pcie,
@@ -436,7 +535,12 @@ def main():
         log(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms/step")
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, one utterance)")
-            line["cpu_baseline"] = cpu_baseline(L, args.frames_per_phone, args.vocoder)
+            line["cpu_baseline"], oracle_out = cpu_baseline(L, args.frames_per_phone, args.vocoder, scales)
+        else:
+            oracle_out = None
+        if use_native:
+            log("verify: utterance 0 of the last timed step against a B = 1 run" + (" and the CPU oracle" if oracle_out else ""))
+            line["verify"] = verify_against_single_run(pipe, last_out, last_wav, packed, z_sq, scales, B, oracle_out)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

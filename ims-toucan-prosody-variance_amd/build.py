@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libtoucan_hip.so")
-SOURCES = ["conv1d.hip", "resblock.hip", "rowops.hip", "attention.hip", "attention_mfma.hip", "sequence_ops.hip", "capi.hip", "pipeline.hip", "style.hip", "wavenet.hip", "ffn.hip"]
+SOURCES = ["conv1d.hip", "resblock.hip", "rowops.hip", "attention_mfma.hip", "sequence_ops.hip", "capi.hip", "pipeline.hip", "style.hip", "wavenet.hip", "ffn.hip"]
 
 
 def _hipcc():

@@ -92,7 +92,9 @@ class TtsConfig(C.Structure):
 
 
 IO_X_BF16, IO_Y_BF16, IO_RES_BF16, IO_F16 = 1, 2, 4, 8
-IO_SPLIT_K = 16  # tts_conv1d, fp32: the caller accepts the split-K form on small grids (the acoustic model does)
+IO_SPLIT_K = 16  # tts_conv1d, fp32: the caller accepts the split-K form on small grids (the frame stages of the fp32 acoustic model do)
+IO_SPLIT_K_ALWAYS = 32  # ... at every grid size (its phoneme stages: one arithmetic upstream of the rounded durations whatever the batch)
+ATT_KEY_SPLIT, ATT_KEY_SPLIT_ALWAYS = 1, 2  # tts_relpos_attention flags (include/toucan_tts.h)
 
 # symbol -> (restype, argtypes); mirrors include/toucan_tts.h one to one
 PROTOTYPES = {
@@ -115,7 +117,7 @@ PROTOTYPES = {
     "tts_l2_normalize": (C.c_int, [_p, _p, _i, _i, _p]),
     "tts_groupnorm": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _i, _i, _p, _p]),
     "tts_groupnorm_workspace_floats": (C.c_int64, [_i, _i, _i]),
-    "tts_relpos_attention": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
+    "tts_relpos_attention": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _i, _p]),
     "tts_relpos_attention_f16": (C.c_int, [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "tts_dwconv_swish": (C.c_int, [_p, _i, _p, _i, _p, _p, _i, _i, _p, _i, _i, _p]),
     "tts_duration_from_log": (C.c_int, [_p, _p, _i, _p]),
@@ -137,6 +139,7 @@ PROTOTYPES = {
     "tts_destroy": (C.c_int, [_p]),
     "tts_load_weights": (C.c_int, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _i]),
     "tts_workspace_bytes": (C.c_int64, [_p, _i, _i, _i]),
+    "tts_workspace_claimed": (C.c_int64, [_p]),
     "tts_encoder": (C.c_int, [_p, _p, _p, _p, _p, _i, _p]),
     "tts_variance_predictors": (C.c_int, [_p, _p, _p, _p, _p]),
     "tts_control_and_regulate": (C.c_int, [_p, _f, _f, _f, _f, _p, _p]),
@@ -156,7 +159,7 @@ PROTOTYPES = {
 }
 
 _LIB = None
-ABI_VERSION = 13  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
+ABI_VERSION = 14  # include/toucan_tts.h TTS_ABI_VERSION: struct layouts and prototypes mirrored below
 
 
 class ToucanHipError(RuntimeError):

@@ -2,8 +2,8 @@
 //
 //   s[i, j] = ((q_i + u_h) . k_j  +  (q_i + v_h) . P_h[i - j]) / sqrt(dk),  softmax over the utterance's keys,  ctx = s . v
 //
-// Same contract as relpos_attention_kernel (attention.hip, Layers/Attention.py:159-198); this version moves the three
-// contractions to v_mfma_f32_32x32x2_f32 and keeps the online softmax in registers:
+// Layers/Attention.py:159-198 (rel_shift :138-157 folded into the index i - j); the three contractions run on
+// v_mfma_f32_32x32x2_f32 and the online softmax stays in registers:
 //
 //   * one workgroup = 4 wavefronts = 128 consecutive queries of one (utterance, head); each wavefront owns 32 queries.
 //     K, V (32 keys) and the 159-row window of the position table are staged in LDS once per key tile for all 4 waves.
@@ -411,15 +411,19 @@ int relpos_attention_f16(const float* qkv, int ld_qkv, const float* ptab, int pm
 }
 
 int relpos_attention_mfma(const float* qkv, int ld_qkv, const float* ptab, int pmax, const float* bias_u, const float* bias_v,
-                          float* ctx, int ld_ctx, int heads, int dk, const TtsTile* tiles, int n_tiles, int tile_rows, hipStream_t st) {
+                          float* ctx, int ld_ctx, int heads, int dk, const TtsTile* tiles, int n_tiles, int tile_rows, int flags, hipStream_t st) {
   TTS_CHECK_ARG(dk == AM_DK, "relpos_attention: head dim %d unsupported (48 only)", dk);
   TTS_CHECK_ARG(tile_rows == AM_QT, "relpos_attention(mfma): tile table must use %d rows, got %d", AM_QT, tile_rows);
   TTS_CHECK_ARG((ld_qkv & 3) == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)ptab & 15) == 0, "relpos_attention: alignment");
   TTS_CHECK_ARG((ld_ctx & 3) == 0 && ((uintptr_t)ctx & 15) == 0, "relpos_attention: ctx alignment");
   if (n_tiles == 0) return TTS_OK;
   // batch 1: 4 (encoder) or 20 (decoder, 640 frames) workgroups with a dependent chain of 104 fp32 MFMAs per 32 keys each -
-  // the key-split form puts 4x the workgroups on the chip (its result differs from the plain form's at rounding-order level)
-  const bool split = (long long)n_tiles * heads <= 64 && std::getenv("TOUCAN_NO_ATTENTION_SPLIT") == nullptr;
+  // the key-split form puts 4x the workgroups on the chip.  Its result differs from the plain form's at rounding-order level, so
+  // the CALLER chooses (include/toucan_tts.h): never (flags 0: the fp32 layers of the 16-bit configurations, whose results are
+  // bit for bit independent of the batch), on small grids (TTS_ATT_KEY_SPLIT: the decoder of the fp32 configuration) or always
+  // (TTS_ATT_KEY_SPLIT_ALWAYS: its encoder - upstream of the rounded durations, one arithmetic whatever the batch)
+  const bool split = ((flags & TTS_ATT_KEY_SPLIT_ALWAYS) || ((flags & TTS_ATT_KEY_SPLIT) && (long long)n_tiles * heads <= 64)) &&
+                     std::getenv("TOUCAN_NO_ATTENTION_SPLIT") == nullptr;
   const size_t lds = (size_t)(2 * (split ? 4 : 1) * AM_KT * AM_PITCH + (AM_PW + 1) * AM_PITCH + 4 * 64 * AM_GP) * sizeof(float);
   if (split) {
     static unsigned long long lds_raised = 0;  // per device (common.h)

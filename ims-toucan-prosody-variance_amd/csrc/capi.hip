@@ -31,10 +31,8 @@ int l2_normalize(const float*, float*, int, int, hipStream_t);
 int groupnorm(const float*, int, float*, int, const float*, const float*, int, int, float, int, const float*, int, const int*,
               const int*, int, int, float*, hipStream_t);
 long groupnorm_workspace_floats(int, int, int);
-int relpos_attention(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
-                     int, hipStream_t);
 int relpos_attention_mfma(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
-                          int, hipStream_t);
+                          int, int, hipStream_t);
 int relpos_attention_f16(const float*, int, const float*, int, const float*, const float*, float*, int, int, int, const TtsTile*, int,
                           int, hipStream_t);
 int dwconv_swish(const float*, int, float*, int, const float*, const float*, int, int, const TtsTile*, int, int, hipStream_t);
@@ -114,11 +112,8 @@ int64_t tts_groupnorm_workspace_floats(int32_t n_seq, int32_t max_len, int32_t g
 
 int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u, const float* bias_v,
                          float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk, const TtsTile* tiles, int32_t n_tiles,
-                         int32_t tile_rows, tts_stream_t stream) {
-  // 128-row tiles: matrix-core kernel (attention_mfma.hip); 64-row tiles: the VALU kernel (attention.hip)
-  if (tile_rows == 128)
-    return tts::relpos_attention_mfma(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
-  return tts::relpos_attention(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, ST(stream));
+                         int32_t tile_rows, int32_t flags, tts_stream_t stream) {
+  return tts::relpos_attention_mfma(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, flags, ST(stream));
 }
 
 int tts_relpos_attention_f16(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u, const float* bias_v,

@@ -694,27 +694,38 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
 // Split-K form for fp32 convs whose small-batch grid is still a handful of workgroups (batch 1: the WaveNet in-layer of the
 // flow is 15 workgroups of the 64 x 64 form, and each of its wavefronts then runs 960 dependent v_mfma_f32_32x32x2_f32 -
 // 61 k cycles - alone on its SIMD while 240 CUs idle).  Here a workgroup owns a 32 x 32 output tile (both halves in the dual
-// modes) and its four wavefronts split the contraction: k-step s = (tap, group of 8 channels) goes to wavefront s % 4, every
+// modes) and its four wavefronts split the contraction: k-step s = (tap, group of 16 channels) goes to wavefront s % 4, every
 // wavefront streams its own operands LDS-free like gemm_rows_kernel (any number of taps: a tap is a row offset, rows outside
 // the utterance contribute zero), the three partial tiles meet in LDS and wavefront 0 runs the shared epilogue.  16x the
-// wavefronts of the 64 x 64 form on the same work; T16 (v_mfma_f32_16x16x4_f32, 16 x 16 tiles, 16 channels per k-step) 64x,
-// for the grids that are still under one workgroup per two CUs in the 32 x 32 form (measured: the fp32 matrix instructions of
-// one wavefront, not the operand stream, set the time - ~50 ns per 32x32x2 - so the only lever is more wavefronts).  The accumulation order differs from the other forms (four interleaved
-// partial sums), so a caller opts in per launch with TTS_IO_SPLIT_K: the acoustic model does (results agree to rounding-order
-// level, which is what the fp32 configuration promises); the vocoder does not (chunked == whole, bit for bit).
+// wavefronts of the 64 x 64 form on the same work; T16 (v_mfma_f32_16x16x4_f32, 16 x 16 tiles) 64x, for the grids that are
+// still under one workgroup per two CUs in the 32 x 32 form (measured: the fp32 matrix instructions of one wavefront, not the
+// operand stream, set the time - ~50 ns per 32x32x2 - so the only lever is more wavefronts).
+// ONE accumulation order for both tile sizes: an output element is the sum of four partial sums (wavefront w: the k-steps
+// w, w + 4, ...), each a chain of fused multiply-adds over its steps' channels in the order c, c + 4, c + 8, c + 12 for
+// c = 0 .. 3 of a 16-channel group - which is what one 16x16x4 instruction per c does, and what two 32x32x2 instructions per c
+// do (channels (c, c + 4), then (c + 8, c + 12): the matrix instructions are k-ordered fma chains).  So a launch's result
+// does not depend on which of the two the grid heuristics pick (tests/test_gpu_kernels.py asserts bit equality).  It does
+// differ from the tiled forms (one chain over all channels), so a caller opts in per launch: TTS_IO_SPLIT_K takes this form on
+// small grids only (the frame stages of the fp32 acoustic model: results agree with the tiled forms to rounding-order level,
+// which is what the fp32 configuration promises for the mel); TTS_IO_SPLIT_K_ALWAYS takes it at EVERY grid size (the
+// phoneme stages of the fp32 acoustic model: the duration predictor rounds exp(log d) to integers, so everything upstream of it
+// keeps one arithmetic whatever the batch - an utterance's frame count, pitch and energy are bit for bit the same at B = 1, in
+// a batch of 32 and in an N-rank shard); the vocoder never does (chunked == whole, bit for bit).
 // ------------------------------------------------------------------------------------------------
 template <bool DUAL, bool T16>
 __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc d) {
   constexpr int NH = DUAL ? 2 : 1;
   constexpr int T = T16 ? 16 : 32;   // rows and columns of the workgroup's output tile
-  constexpr int KQ = 64 / T;         // k-slots of one matrix instruction (lane / T)
-  constexpr int GC = 4 * KQ;         // channels per k-step: one float4 per lane feeds four matrix instructions
+  constexpr int GC = 16;             // channels per k-step (both tile sizes: one accumulation order, see above)
+  constexpr int NA = T16 ? 1 : 2;    // float4 activation loads per lane and k-step (T16: 4 k-slots x 4 channels; 32 x 32: 2 k-slots x 4 channels, twice)
+  constexpr int NB = 4 * NA;         // weight dwords per lane, half and k-step
   constexpr int AR = T16 ? 4 : 16;   // accumulator registers per lane
 #ifndef TTS_SPLITK_DEPTH
 #define TTS_SPLITK_DEPTH 4
 #endif
-  constexpr int DEPTH = TTS_SPLITK_DEPTH;  // k-steps in flight per wavefront (4, 6, 8 measured alike: the stream is not latency-bound)
-  constexpr int L = 1 + 4 * NH;      // loads per k-step
+  constexpr int DEPTH = T16 ? TTS_SPLITK_DEPTH : TTS_SPLITK_DEPTH / 2;  // k-steps in flight per wavefront (the same bytes either way; 4, 6, 8 measured alike)
+  constexpr int L = NA + NB * NH;    // loads per k-step
+  static_assert((DEPTH - 1) * L <= 63, "vmcnt is a 6-bit count");
   using Acc = typename std::conditional<T16, f32x4, f32x16>::type;
   __shared__ float part[3][NH][AR][64];
   const int subs = d.tile_rows / T;  // row blocks of this kernel per tile of the table (any of the table's forms: 64, 128, 256 rows)
@@ -739,13 +750,13 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
 #define TTS_GLOAD32(dst_, ptr_) asm volatile("global_load_dword %0, %1, off" : "=v"(dst_) : "v"(ptr_) : "memory")
 #define TTS_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n_) : "memory")
 #define TTS_PIN(r_) asm volatile("" : "+v"(r_))
-  const int G = d.cin / GC;                       // k-steps per tap (dispatch: cin % GC == 0, G >= 4)
+  const int G = d.cin / GC;                       // k-steps per tap (dispatch: cin % 16 == 0, cin >= 32)
   const int S = d.taps * G;                       // k-steps of the whole contraction
   const int n_w = S > wave ? (S - wave + 3) >> 2 : 0;  // ... of this wavefront: s = wave, wave + 4, ...
-  int tap_r = 0, g_r = wave;                      // the next step to request
+  int tap_r = wave / G, g_r = wave % G;           // the next step to request (G may be smaller than 4)
   const size_t wrow = (size_t)d.wn * 4, whalf = (size_t)d.half_pad * 4;
-  u32x4 a[DEPTH];
-  unsigned int b[NH][DEPTH][4];
+  u32x4 a[DEPTH][NA];
+  unsigned int b[NH][DEPTH][NB];
   bool inside[DEPTH];
   // requests the step (tap_r, g_r) and moves on; past the end it re-requests the last step of the contraction with `inside`
   // false, i.e. as a row of zeros: the stream stays branch-free, every wait count exact, and the matrix instructions
@@ -758,21 +769,27 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
     r = r < tile.seq_begin ? tile.seq_begin : (r >= tile.seq_end ? tile.seq_end - 1 : r);
     const char* xp = reinterpret_cast<const char*>(d.x) + ((size_t)r * d.ldx + gg * GC + kq * 4) * 4;
     const char* wp = reinterpret_cast<const char*>(d.w) + (((size_t)tp * d.cin_pad + gg * GC + kq * 4) * d.wn + col) * 4;
-    TTS_GLOAD128(a[slot], xp);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) TTS_GLOAD128(a[slot][q], xp + q * 32);  // (32 x 32: the second float4 holds the channels 8 further on)
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) TTS_GLOAD32(b[h][slot][j], wp + j * wrow + h * whalf);
-    g_r += live ? 4 : 0;
-    if (g_r >= G) { g_r -= G; ++tap_r; }
+      for (int q = 0; q < NA; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) TTS_GLOAD32(b[h][slot][4 * q + j], wp + (8 * q + j) * wrow + h * whalf);
+    if (live) {
+      g_r += 4;
+      while (g_r >= G) { g_r -= G; ++tap_r; }
+    }
   };
   auto arrive = [&](int slot) __attribute__((always_inline)) {
     TTS_WAIT_VM((DEPTH - 1) * L);
-    TTS_PIN(a[slot]);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) TTS_PIN(a[slot][q]);
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) TTS_PIN(b[h][slot][j]);
+      for (int j = 0; j < NB; ++j) TTS_PIN(b[h][slot][j]);
   };
 #pragma unroll
   for (int u = 0; u < DEPTH; ++u) request(u);
@@ -780,32 +797,38 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
 #pragma unroll
     for (int u = 0; u < DEPTH; ++u) {
       arrive(u);
-      float av[4], bv[NH][4];
+      float av[NA][4], bv[NH][NB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        av[j] = inside[u] ? pre_activation(u2f(a[u][j]), d.pre_act, d.pre_slope) : 0.0f;
+      for (int q = 0; q < NA; ++q)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) bv[h][j] = u2f(b[h][u][j]);
-      }
-      // matrix instruction j contracts the channels gg * GC + 4 q + j, q = 0 .. KQ-1 (k-slot q is supplied by the lanes with kq == q)
+        for (int j = 0; j < 4; ++j) av[q][j] = inside[u] ? pre_activation(u2f(a[u][q][j]), d.pre_act, d.pre_slope) : 0.0f;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bv[h][j] = u2f(b[h][u][j]);
+      // channel c = j of the group: T16 contracts c, c + 4, c + 8, c + 12 in one instruction (k-slot q = lane / 16 supplies c + 4 q);
+      // the 32 x 32 form in two (k-slots supply c, c + 4 - then c + 8, c + 12 from the second load): the same fma chain
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          if constexpr (T16) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[h][j], acc[h], 0, 0, 0);
-          else acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[h][j], acc[h], 0, 0, 0);
-        }
+        for (int q = 0; q < NA; ++q)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) {
+            if constexpr (T16) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][j], bv[h][4 * q + j], acc[h], 0, 0, 0);
+            else acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bv[h][4 * q + j], acc[h], 0, 0, 0);
+          }
       request(u);
     }
   }
   TTS_WAIT_VM(0);  // drain the tail requests: their destination registers stay allocated (pinned) until here
 #pragma unroll
   for (int u = 0; u < DEPTH; ++u) {
-    TTS_PIN(a[u]);
+#pragma unroll
+    for (int q = 0; q < NA; ++q) TTS_PIN(a[u][q]);
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) TTS_PIN(b[h][u][j]);
+      for (int j = 0; j < NB; ++j) TTS_PIN(b[h][u][j]);
   }
 #undef TTS_GLOAD128
 #undef TTS_GLOAD32
@@ -926,22 +949,24 @@ static bool gemm_rows_ok(const TtsConvDesc& d) {
   return std::getenv("TOUCAN_NO_GEMM_ROWS") == nullptr;  // escape hatch for A/B measurements
 }
 
-// the split-K form: fp32, opted in by the caller (TTS_IO_SPLIT_K), a grid of at most 128 workgroups if cut into 64 x 64 tiles and a
+// the split-K form: fp32, opted in by the caller.  TTS_IO_SPLIT_K: a grid of at most 128 workgroups if cut into 64 x 64 tiles and a
 // contraction of at least 64 products per output (measured at batch 1 x 128 phonemes, the whole acoustic pass: 6.4 ms with a
-// minimum depth of 256, 5.2 ms with 128, 5.0 ms with 64 - even the 192-deep 1-tap convs are faster on 4-16x the wavefronts)
+// minimum depth of 256, 5.2 ms with 128, 5.0 ms with 64 - even the 192-deep 1-tap convs are faster on 4-16x the wavefronts).
+// TTS_IO_SPLIT_K_ALWAYS: whatever the grid (the eligibility below then depends on the conv alone, never on the batch).
 static bool splitk_ok(const TtsConvDesc& d, int cols) {
-  if (d.compute != 0 || !(d.io_flags & TTS_IO_SPLIT_K) || (d.io_flags & TTS_IO_X_BF16) || d.pre_act == TTS_PRE_SNAKE) return false;
-  if ((d.cin & 7) != 0 || d.cin < 32 || (d.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0 || (cols & 31) != 0) return false;
+  if (d.compute != 0 || !(d.io_flags & (TTS_IO_SPLIT_K | TTS_IO_SPLIT_K_ALWAYS)) || (d.io_flags & TTS_IO_X_BF16) || d.pre_act == TTS_PRE_SNAKE) return false;
+  if ((d.cin & 15) != 0 || d.cin < 32 || (d.ldx & 3) != 0 || (reinterpret_cast<uintptr_t>(d.x) & 15) != 0 || (cols & 31) != 0) return false;
   static const int min_depth = std::getenv("TOUCAN_SPLIT_K_MIN") ? std::atoi(std::getenv("TOUCAN_SPLIT_K_MIN")) : 64;  // (A/B runs)
   static const int max_grid = std::getenv("TOUCAN_SPLIT_K_GRID") ? std::atoi(std::getenv("TOUCAN_SPLIT_K_GRID")) : 128;  // (A/B runs)
-  if ((long long)d.taps * d.cin < min_depth || (long long)d.n_tiles * (d.tile_rows / 64) * ((cols + 63) / 64) > max_grid) return false;
+  if ((long long)d.taps * d.cin < min_depth) return false;
+  if (!(d.io_flags & TTS_IO_SPLIT_K_ALWAYS) && (long long)d.n_tiles * (d.tile_rows / 64) * ((cols + 63) / 64) > max_grid) return false;
   return std::getenv("TOUCAN_NO_SPLIT_K") == nullptr;  // escape hatch for A/B measurements
 }
 
 static int launch_splitk(const TtsConvDesc& d, int cols, hipStream_t st) {
   const bool dual = d.mode != TTS_MODE_LINEAR;
-  // 16 x 16 tiles while the 32 x 32 grid is at most 128 workgroups (and the channels come in whole groups of 16)
-  if ((d.cin & 15) == 0 && d.cin >= 64 && (long long)d.n_tiles * (d.tile_rows / 32) * (cols / 32) <= (std::getenv("TOUCAN_SPLIT_K16_GRID") ? std::atoi(std::getenv("TOUCAN_SPLIT_K16_GRID")) : 128) && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
+  // 16 x 16 tiles while the 32 x 32 grid is at most 128 workgroups (a speed choice only: both sizes sum in the same order)
+  if (d.cin >= 64 && (long long)d.n_tiles * (d.tile_rows / 32) * (cols / 32) <= (std::getenv("TOUCAN_SPLIT_K16_GRID") ? std::atoi(std::getenv("TOUCAN_SPLIT_K16_GRID")) : 128) && std::getenv("TOUCAN_NO_SPLIT_K16") == nullptr) {
     dim3 grid(d.n_tiles * (d.tile_rows / 16), cols / 16), block(256);
     if (dual) hipLaunchKernelGGL((conv_splitk_f32_kernel<true, true>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((conv_splitk_f32_kernel<false, true>), grid, block, 0, st, d);

@@ -110,8 +110,11 @@ struct Handle {
   std::unordered_map<std::string, TileTab> tile_cache;
   std::unordered_map<std::string, int*> bounds_cache;
   int small_tile_blocks = 1536;
-  bool split_k = false;           // set by the acoustic stage entries, cleared by the vocoder's: in the fp32 configuration the convs of the
-                                  // acoustic model may take the split-K form on small grids (TTS_IO_SPLIT_K; the vocoder keeps chunked == whole)
+  int split_mode = 0;             // set by the stage entries; the fp32 configuration only.  2 (phoneme stages: encoder, predictors): split-K convs
+                                  // and key-split attention at EVERY grid size - durations are a rounding of exp(log d), so everything upstream
+                                  // of them keeps one arithmetic whatever the batch (an utterance's frame count cannot depend on the batch or
+                                  // shard it is in); 1 (frame stages): the split forms on small grids only (TTS_IO_SPLIT_K / TTS_ATT_KEY_SPLIT:
+                                  // the mel agrees to rounding order across batch sizes); 0 (vocoder: chunked == whole, bit for bit)
   bool no_fused_wavenet = false;  // TOUCAN_NO_FUSED_WAVENET: A/B switch, same meaning as in engine.py
   bool no_fused_ffn = false;      // TOUCAN_NO_FUSED_FFN: likewise
   bool no_f16_attention = false;  // TOUCAN_NO_F16_ATTENTION: likewise
@@ -158,7 +161,7 @@ int arena_reserve(Arena& a, size_t bytes, hipStream_t st) {
     a.base = nullptr;
     a.cap = 0;
   }
-  const size_t want = bytes + bytes / 8 + (1 << 20);
+  const size_t want = bytes + bytes / 8 + (1 << 20);  // (= with_growth_slack(bytes): tts_workspace_bytes counts it)
   TTS_TRY(hip_ok(hipMalloc(reinterpret_cast<void**>(&a.base), want), "workspace: hipMalloc"));
   a.cap = want;
   return TTS_OK;
@@ -364,8 +367,8 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
   // the fp32 configuration only: the fp32 layers of a 16-bit configuration keep one accumulation order at every batch size (an
   // utterance's result there does not depend on the batch it is in, bit for bit - tests/test_gpu_e2e.py asserts it)
-  if (h->split_k && !o.no_split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32)
-    d.io_flags |= TTS_IO_SPLIT_K;
+  if (h->split_mode && !o.no_split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32)
+    d.io_flags |= h->split_mode == 2 ? TTS_IO_SPLIT_K_ALWAYS : TTS_IO_SPLIT_K;
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
     const bool dual = cw.mode != TTS_MODE_LINEAR;
@@ -516,7 +519,8 @@ int conformer(Handle* h, int stack, float* x, const Layout& l, Arena& a, hipStre
     if (b16 == 16 && !h->no_f16_attention)  // (16-bit configurations: the contractions on the fp16 matrix cores)
       TTS_TRY(tts_relpos_attention_f16(qkv, 3 * ATT, h->ptab[stack] + bi * prow, h->pmax, b.u, b.v, ctx, ATT, HEADS, DK, t128.dev, t128.n, 128, st));
     else
-      TTS_TRY(tts_relpos_attention(qkv, 3 * ATT, h->ptab[stack] + bi * prow, h->pmax, b.u, b.v, ctx, ATT, HEADS, DK, t128.dev, t128.n, 128, st));
+      TTS_TRY(tts_relpos_attention(qkv, 3 * ATT, h->ptab[stack] + bi * prow, h->pmax, b.u, b.v, ctx, ATT, HEADS, DK, t128.dev, t128.n, 128,
+                                   b16 == 16 ? 0 : (h->split_mode == 2 ? TTS_ATT_KEY_SPLIT_ALWAYS : (h->split_mode == 1 ? TTS_ATT_KEY_SPLIT : 0)), st));
     TTS_TRY(conv(h, b.out, T2(ctx, ATT), T2(x, ATT), l, st, res1));
     // convolution module (:119-125, Convolution.py:31-55)
     TTS_TRY(tts_layernorm(x, ATT, ln, ATT, b.ln_g[2], b.ln_b[2], R, ATT, 1e-12f, st));
@@ -537,6 +541,31 @@ int conformer(Handle* h, int stack, float* x, const Layout& l, Arena& a, hipStre
 }
 
 size_t conformer_bytes(size_t R) { return R * (ATT * 4 * 4 + 1536 * 4 + 3 * ATT * 4) + 8 * 256; }
+
+// Arena sizes: ONE set of expressions for the stage entries (what they reserve) and for tts_workspace_bytes (what it promises).
+size_t phone_arena_bytes(size_t R, size_t B) {
+  return conformer_bytes(R) + R * (100 + 3 * ATT + 6 * 256 + 16) * 4 + B * (64 + 2 * ATT + 24 * 256 + 8) * 4 + (1 << 16);
+}
+size_t frame_arena_bytes(size_t RF) {
+  return conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 3 * 80 + 2 * 256 + ATT + 160 + 4 * ATT + ATT + 8 * ATT + 64) * 4 + (64 << 20);
+}
+// vocoder: R packed mel rows.  Arena 1 holds the pre-conv output [R, 512] fp32 and later the stages 1 and 3, arena 0 the stages 0 and 2
+// (a stage reads its input from the other arena).  Per stage: the up-sampled tensor, the stage output and two ping-pong buffers of
+// [rows, channels] - plus, where the residual steps are not fused (fp32 configuration; 256 channels), the conv intermediate and
+// for BigVGAN the two stand-alone snake outputs.  16-bit configurations keep 16-bit stage tensors.
+size_t vocoder_stage_bytes(size_t R, int stage, bool fused_mode, bool big) {
+  static const int UPS[4] = {8, 48, 192, 384};
+  const size_t ch = 256 >> stage, rows = R * UPS[stage], se = fused_mode ? 2 : 4;
+  const bool fused = fused_mode && ch <= 128;
+  const size_t tensors = 4 + (fused ? 0 : (big ? 3 : 1));
+  return tensors * (((rows * ch * se) + 255) & ~(size_t)255) + (1 << 20);
+}
+size_t vocoder_arena_bytes(size_t R, int arena, bool fused_mode, bool big) {
+  size_t m = arena == 1 ? R * 512 * 4 + (1 << 20) : 0;
+  for (int i = arena; i < 4; i += 2) m = std::max(m, vocoder_stage_bytes(R, i, fused_mode, big));
+  return m;
+}
+size_t with_growth_slack(size_t bytes) { return bytes + bytes / 8 + (1 << 20); }  // what arena_reserve allocates for a request
 
 int predictor(Handle* h, const char* name, int layers, int first_cln, float* out, hipStream_t st) {
   const Layout& l = h->lp;
@@ -638,19 +667,22 @@ int pipeline_load(Handle* h, const char* name, const void* host, const int64_t* 
   return TTS_OK;
 }
 
-// upper bound of the workspace a batch of B utterances with at most Lmax phonemes / Tmax frames each will claim
+// upper bound of the workspace a batch of B utterances with at most Lmax phonemes / Tmax frames each will claim: the sum of what the
+// stage entries reserve for such a batch (same expressions), arena growth slack included (tts_workspace_claimed reports the real sum)
 long long pipeline_workspace_bytes(const Handle* h, int B, int Lmax, int Tmax) {
   if (!h || B <= 0) return 0;
-  const size_t RP = (size_t)B * Lmax, RF = (size_t)B * (Tmax + 1);
-  size_t phone = conformer_bytes(RP) + RP * (62 + 100 + 3 * ATT + 6 * 256 + 16) * 4 + (size_t)B * (64 + 2 * ATT + 24 * 256) * 4 + (1 << 16);
-  size_t frame = conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 80 * 3 + 2 * 256 + ATT + 160 + 4 * ATT + ATT + 8 * ATT) * 4 + (64 << 20);
-  size_t voc = 0;
+  const size_t RP = (size_t)B * Lmax, RF = (size_t)B * (Tmax + 1);  // (frame layouts start every utterance on an even row)
+  size_t total = with_growth_slack(phone_arena_bytes(RP, B)) + with_growth_slack(frame_arena_bytes(RF));
   if (h->cfg.vocoder) {
-    const size_t e = h->cfg.precision == TTS_COMPUTE_F32 ? 4 : 2;
-    voc = RF * 512 * 4 + RF * 384 * 4;                      // pre conv output, waveform
-    voc += 2 * (RF * 8 * 256 * e * 8);                      // per stage: rows x ch is at most 8 x 256 x frames; up to 8 tensors of it
+    const bool fused_mode = h->cfg.precision != TTS_COMPUTE_F32, big = h->cfg.vocoder == 2;
+    for (int a = 0; a < 2; ++a) total += with_growth_slack(vocoder_arena_bytes(RF, a, fused_mode, big));
   }
-  return (long long)(phone + frame + voc);
+  return (long long)total;
+}
+
+long long pipeline_workspace_claimed(const Handle* h) {
+  if (!h) return 0;
+  return (long long)(h->phone.cap + h->frame.cap + h->voc[0].cap + h->voc[1].cap);
 }
 
 // ---- stage A.1: encoder ----------------------------------------------------------------------------------------------
@@ -658,14 +690,13 @@ int pipeline_encoder(Handle* h, const float* text, const float* utt_emb, const i
                      hipStream_t st) {
   TTS_CHECK_ARG(h && text && phone_lengths && B > 0, "tts_encoder: bad arguments");
   TTS_CHECK_ARG(!h->cfg.multispeaker || utt_emb, "tts_encoder: the multi-speaker checkpoint needs utterance embeddings");
-  h->split_k = true;
+  h->split_mode = 2;
   h->lp = Layout::make(phone_lengths, B, 1);
   h->B = B;
   h->text = text;
   h->have_flow = false;
   const int R = h->lp.total;
-  const size_t bytes = conformer_bytes(R) + (size_t)R * (100 + 3 * ATT + 6 * 256 + 16) * 4 + (size_t)B * (64 + 2 * ATT + 24 * 256 + 8) * 4 + (1 << 16);
-  TTS_TRY(arena_reserve(h->phone, bytes, st));
+  TTS_TRY(arena_reserve(h->phone, phone_arena_bytes(R, B), st));
   TTS_TRY(ensure_ptabs(h, st));
   Arena& a = h->phone;
   int bn = B;
@@ -727,7 +758,7 @@ int pipeline_encoder(Handle* h, const float* text, const float* utt_emb, const i
 // ---- stage A.2: pitch / energy / duration predictors (gold values replace a prediction) --------------------------------
 int pipeline_predictors(Handle* h, const float* gold_pitch, const float* gold_energy, const int* gold_dur, hipStream_t st) {
   TTS_CHECK_ARG(h && h->enc, "tts_variance_predictors: run tts_encoder first");
-  h->split_k = true;
+  h->split_mode = 2;
   const int R = h->lp.total, B = h->B;
   Arena& a = h->phone;
   if (h->cfg.multispeaker && !(gold_pitch && gold_energy && gold_dur)) {
@@ -774,7 +805,7 @@ int pipeline_control_regulate(Handle* h, float duration_scale, float pitch_scale
   }
   h->lf = Layout::make(h->frames.data(), B, 2);  // even begins: the Glow squeeze is a pure re-view
   const size_t RF = h->lf.total;
-  TTS_TRY(arena_reserve(h->frame, conformer_bytes(RF) + RF * ((80 + ATT) + 2 * ATT + 3 * 80 + 2 * 256 + ATT + 160 + 4 * ATT + ATT + 8 * ATT + 64) * 4 + (64 << 20), st));
+  TTS_TRY(arena_reserve(h->frame, frame_arena_bytes(RF), st));
   Arena& a = h->frame;
   TTS_ALLOC(cat, a, float, RF * (80 + ATT));  // [refined mel | up-sampled text] = g_proj input
   TTS_TRY(hip_ok(hipMemsetAsync(cat, 0, RF * (80 + ATT) * 4, st), "clear frame buffer"));
@@ -795,7 +826,7 @@ int pipeline_control_regulate(Handle* h, float duration_scale, float pitch_scale
 // ---- stage B.1: decoder + feat_out --------------------------------------------------------------------------------------
 int pipeline_decoder(Handle* h, hipStream_t st) {
   TTS_CHECK_ARG(h && h->dec, "tts_decoder: run tts_control_and_regulate first");
-  h->split_k = true;
+  h->split_mode = 1;
   TTS_TRY(conformer(h, 1, h->dec, h->lf, h->frame, st));
   ConvW fo;
   TTS_TRY(conv_of(h, "feat_out", &fo));
@@ -808,7 +839,7 @@ int pipeline_decoder(Handle* h, hipStream_t st) {
 // ---- stage B.2: PostNet + residual -------------------------------------------------------------------------------------
 int pipeline_postnet(Handle* h, hipStream_t st) {
   TTS_CHECK_ARG(h && h->mel0, "tts_postnet: run tts_decoder first");
-  h->split_k = true;
+  h->split_mode = 1;
   const Layout& l = h->lf;
   const int RF = l.total;
   Arena& a = h->frame;
@@ -849,7 +880,7 @@ int pipeline_postnet(Handle* h, hipStream_t st) {
 int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
   TTS_CHECK_ARG(h && h->mel == h->cat && h->cat, "tts_postflow: run tts_postnet first");
   TTS_CHECK_ARG(z_noise, "tts_postflow: z_noise is required");
-  h->split_k = true;
+  h->split_mode = 1;
   const Layout ls = h->lf.halved();
   const int RF = h->lf.total, RS = RF / 2;
   Arena& a = h->frame;
@@ -944,7 +975,7 @@ int pipeline_vocoder(Handle* h, int kind, const float* mel, int ld_mel, const in
                      hipStream_t st) {
   TTS_CHECK_ARG(h && mel && frame_begins && frame_counts && wav && B > 0, "tts_vocoder: bad arguments");
   TTS_CHECK_ARG(kind == h->cfg.vocoder, "tts_vocoder: the handle was created for vocoder %d, not %d", h->cfg.vocoder, kind);
-  h->split_k = false;
+  h->split_mode = 0;
   const bool big = kind == 2;
   Layout l;
   for (int u = 0; u < B; ++u) {
@@ -958,7 +989,11 @@ int pipeline_vocoder(Handle* h, int kind, const float* mel, int ld_mel, const in
   const size_t e = b16 / 8;
   size_t R = l.total;
   // stage buffers: x (input of the stage) lives in the other arena
-  TTS_TRY(arena_reserve(h->voc[1], R * 512 * 4 + (1 << 20), st));
+  // both arenas at their size for the whole pass (the larger of the stages each one hosts: a stage would otherwise regrow the arena
+  // its predecessor's input still lives in)
+  const size_t R0 = R;
+  TTS_TRY(arena_reserve(h->voc[1], vocoder_arena_bytes(R0, 1, fused_mode, big), st));
+  TTS_TRY(arena_reserve(h->voc[0], vocoder_arena_bytes(R0, 0, fused_mode, big), st));
   TTS_ALLOC(x0, h->voc[1], float, R * 512);
   ConvW pre;
   TTS_TRY(conv_of(h, "voc.pre", &pre));
@@ -982,7 +1017,7 @@ int pipeline_vocoder(Handle* h, int kind, const float* mel, int ld_mel, const in
     const size_t se = sb / 8;
     Arena& a = h->voc[i & 1];
     const size_t RU = R * u;
-    TTS_TRY(arena_reserve(a, RU * ch * se * 8 + (8 << 20), st));
+    a.reset();  // (sized above; the stage two steps back is dead)
     ConvW up;
     TTS_TRY(conv_of(h, "voc.ups." + std::to_string(i), &up));
     TTS_ALLOC(y, a, char, RU * ch * se);
@@ -1110,6 +1145,7 @@ int tts_load_weights(TtsHandle* h, const char* name, const void* host_ptr, const
 int64_t tts_workspace_bytes(const TtsHandle* h, int32_t B, int32_t Lmax, int32_t Tmax) {
   return tts::pipeline_workspace_bytes(reinterpret_cast<const tts::Handle*>(h), B, Lmax, Tmax);
 }
+int64_t tts_workspace_claimed(const TtsHandle* h) { return tts::pipeline_workspace_claimed(reinterpret_cast<const tts::Handle*>(h)); }
 int tts_encoder(TtsHandle* h, const float* text, const float* utt_emb, const int32_t* lang_ids, const int32_t* phone_lengths, int32_t B,
                 tts_stream_t stream) {
   return tts::pipeline_encoder(H(h), text, utt_emb, lang_ids, phone_lengths, B, ST(stream));

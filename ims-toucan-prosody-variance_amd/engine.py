@@ -70,7 +70,10 @@ class Ops:
             raise capi.ToucanHipError(f"device {str(self.device)!r}: libtoucan_hip.so has no CPU path - construct the engines / the "
                                       f"interface with device='cuda' (the reference's default 'cpu' cannot be served)")
         self.timer = None  # optional profiling.ConvTimer (bench.py): HIP events around selected conv launches
-        self.split_k = False  # the acoustic engine sets it: its fp32 convs may take the split-K form on small grids
+        # fp32 configuration only, set per stage by the acoustic engine (same rule as pipeline.hip's Handle::split_mode): 2 = split-K
+        # convs / key-split attention at every grid size (phoneme stages: everything upstream of the rounded durations keeps one
+        # arithmetic whatever the batch), 1 = on small grids only (frame stages), 0 = never (vocoder: chunked == whole)
+        self.split_k = 0
         self.small_tile_blocks = int(os.environ.get("TOUCAN_SMALL_TILE_BLOCKS", "1536"))  # regular conv grids below this many workgroups switch to the 64 x 64 small-batch form (0: never)
         self._fir_tabs = {}
         self.default_compute = COMPUTE_F32  # convs whose weights carry a 16-bit copy run on bf16 / fp16 MFMA when this is not COMPUTE_F32
@@ -118,7 +121,7 @@ class Ops:
         if split_k and self.split_k and self.default_compute == COMPUTE_F32 and d.compute == COMPUTE_F32:
             # same rule as pipeline.hip conv(): the fp32 configuration only - the fp32 layers of a 16-bit configuration keep one
             # accumulation order at every batch size (an utterance's result there does not depend on the batch it is in, bit for bit)
-            d.io_flags |= capi.IO_SPLIT_K
+            d.io_flags |= capi.IO_SPLIT_K_ALWAYS if self.split_k == 2 else capi.IO_SPLIT_K
         d.tiles, d.n_tiles, d.tile_rows = tiles.data_ptr(), n_tiles, tile_rows
         tm = self.timer
         if tm is not None and tm.wants(cw, d.compute, tile_rows):
@@ -225,13 +228,19 @@ class Ops:
                                           ws.data_ptr(), self.stream()), "tts_groupnorm")
         return y
 
-    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag, tile_rows=128, f16=False):
-        """tile_rows 128: matrix-core kernel (fp32-input MFMA, exact fp32 products; f16: the fp16-MFMA form of the 16-bit
-        configurations); 64: the VALU kernel."""
+    def attention(self, qkv, ptab, pmax, bias_u, bias_v, ctx, rag, tile_rows=128, f16=False, flags=None):
+        """Matrix-core kernels: fp32-input MFMA (exact fp32 products), or f16: the fp16-MFMA form of the 16-bit configurations.
+        flags (fp32 kernel): capi.ATT_KEY_SPLIT / ATT_KEY_SPLIT_ALWAYS; default: by the stage's split mode in the fp32 configuration,
+        0 (the plain form) in the 16-bit ones."""
         tiles, n = rag.tiles(tile_rows)
-        fn, name = (self.lib.tts_relpos_attention_f16, "tts_relpos_attention_f16") if f16 else (self.lib.tts_relpos_attention, "tts_relpos_attention")
-        capi.check(fn(qkv.data_ptr(), _ld(qkv), ptab.data_ptr(), pmax, bias_u.data_ptr(), bias_v.data_ptr(), ctx.data_ptr(), _ld(ctx), HEADS, DK,
-                      tiles.data_ptr(), n, tile_rows, self.stream()), name)
+        args = (qkv.data_ptr(), _ld(qkv), ptab.data_ptr(), pmax, bias_u.data_ptr(), bias_v.data_ptr(), ctx.data_ptr(), _ld(ctx), HEADS, DK,
+                tiles.data_ptr(), n, tile_rows)
+        if f16:
+            capi.check(self.lib.tts_relpos_attention_f16(*args, self.stream()), "tts_relpos_attention_f16")
+            return ctx
+        if flags is None:
+            flags = 0 if self.default_compute != COMPUTE_F32 else {0: 0, 1: capi.ATT_KEY_SPLIT, 2: capi.ATT_KEY_SPLIT_ALWAYS}[self.split_k]
+        capi.check(self.lib.tts_relpos_attention(*args, flags, self.stream()), "tts_relpos_attention")
         return ctx
 
     def dwconv_swish(self, x, y, w, b, c, k, rag):
@@ -386,8 +395,6 @@ class AcousticEngine:
         over 18 blocks overflow otherwise)."""
         # pack_only: only the weight preparation (host tensors for native.NativePipeline to upload), no launch machinery
         self.ops = None if pack_only else Ops(device)
-        if self.ops is not None:
-            self.ops.split_k = True
         self.device = torch.device(device) if pack_only else self.ops.device
         self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
         self.bf16 = bool(bf16)  # a 16-bit MFMA configuration (either format)
@@ -554,6 +561,7 @@ class AcousticEngine:
     def _stage_a(self, text, emb, lang_idx, gold_p, gold_e, gold_d, rag_p, rag_b, scales, taps=None):
         """Conformer.py:92-134, VariancePredictor / DurationPredictor, InferenceToucanTTS.py:214-227."""
         ops = self.ops
+        ops.split_k = 2  # phoneme stages (fp32 configuration): the split forms at every grid size - see Ops.__init__
         R, B = text.shape[0], emb.shape[0]
         e_norm = ops.l2_normalize(emb, ops.empty(B, 64))
         h100 = ops.conv(self.embed0, text, ops.empty(R, 100), rag_p, act=ACT_TANH)
@@ -599,6 +607,7 @@ class AcousticEngine:
     # ---- stage B: length regulator -> decoder -> PostNet -> PostFlow (shapes fixed by the durations) ----------
     def _stage_b(self, enc, p, en, d, z_sq, rag_p, rag_f, taps=None):
         ops, dev = self.ops, self.device
+        ops.split_k = 1  # frame stages (fp32 configuration): the split forms on small grids only
         RF = rag_f.total_rows
         cat = torch.zeros(RF, 80 + ATT, dtype=torch.float32, device=dev)  # [refined mel | upsampled text] = g_proj input
         up = cat[:, 80:]

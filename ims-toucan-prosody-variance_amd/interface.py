@@ -13,8 +13,8 @@ script written against the reference (run_text_to_file_reader.py:8-16) works unc
 
 * ``set_utterance_embedding(path)`` (:103-114): reference audio -> log-mel -> GST style embedding on the GPU (style.py)
 
-What is NOT here (unavailable offline): grapheme-to-phoneme conversion needs espeak-ng / phonemizer (raw text
-raises unless that package is importable), the silero voice-activity trim of the reference audio, plotting.
+What is NOT here (unavailable offline): grapheme-to-phoneme conversion (espeak-ng / phonemizer: raw text
+raises - pass phoneme strings with ``input_is_phones=True``) and the silero voice-activity trim of the reference audio.
 """
 import os
 import wave as _wave
@@ -176,10 +176,15 @@ class ToucanTTSInterface(torch.nn.Module):
                 pitch=None,
                 energy=None,
                 input_is_phones=False,
-                return_plot_as_filepath=False):
+                return_plot_as_filepath=False,
+                z_noise=None):
+        """The reference's signature (ToucanTTSInterface.py:132-143) plus one additive keyword: ``z_noise`` [80, T] - the PostFlow
+        noise 0.8 N(0,1) the reference draws inside the model (Glow.py:363) - so that a call can be reproduced and checked
+        against the oracle; None draws it on the device."""
         with torch.inference_mode():
             phones = self.text2phone.string_to_tensor(text, input_phonemes=input_is_phones)
             wavs = self._synthesize([phones], [self.default_utterance_embedding], [self._lang()],
+                                    z_noise=None if z_noise is None else [z_noise],
                                     durations=None if durations is None else [durations],
                                     pitch=None if pitch is None else [pitch],
                                     energy=None if energy is None else [energy],

@@ -213,7 +213,12 @@ class NativePipeline:
         return out
 
     def workspace_bytes(self, B, Lmax, Tmax):
+        """Upper bound (bytes) of the workspace a batch of that shape will claim - what a caller budgets HBM from."""
         return sum(int(self.lib.tts_workspace_bytes(handle, B, Lmax, Tmax)) for handle in self._handles())
+
+    def workspace_claimed(self):
+        """Bytes the handles' arenas hold right now."""
+        return sum(int(self.lib.tts_workspace_claimed(handle)) for handle in self._handles())
 
     # ---- one ragged batch ---------------------------------------------------------------------------------------------
     def _stream(self):

@@ -55,6 +55,13 @@ typedef struct {
 #define TTS_IO_F16 8      /* the 16-bit tensors named by the three bits above are IEEE fp16 (compute 2) instead of bf16 */
 #define TTS_IO_SPLIT_K 16 /* tts_conv1d, fp32 only: the caller accepts the split-K form when the grid is a handful of workgroups
                              (four interleaved partial sums: the result then depends on the grid at rounding-order level) */
+#define TTS_IO_SPLIT_K_ALWAYS 32 /* tts_conv1d, fp32 only: the split-K form at EVERY grid size wherever the conv itself is eligible
+                             (one arithmetic whatever the batch: the phoneme stages of the fp32 acoustic model, whose rounded durations
+                             must not depend on the batch an utterance is in) */
+/* tts_relpos_attention flags (fp32 kernel): the key-split form - four wavefronts share one block of 32 queries, split the keys
+ * and merge (max, sum, output) in LDS: four interleaved partial sums, i.e. another rounding order than the plain form */
+#define TTS_ATT_KEY_SPLIT 1        /* on grids of at most 64 workgroups (batch 1): the result then depends on the grid at rounding level */
+#define TTS_ATT_KEY_SPLIT_ALWAYS 2 /* at every grid size: one arithmetic whatever the batch */
 #define TTS_COMPUTE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation */
 #define TTS_COMPUTE_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulation (BASELINE.json configs[2]) */
 #define TTS_COMPUTE_F16 2  /* v_mfma_f32_32x32x16_f16, fp32 accumulation (BASELINE.json configs[4]) */
@@ -219,11 +226,11 @@ int64_t tts_groupnorm_workspace_floats(int32_t n_seq, int32_t max_len, int32_t g
  *   s[i,j] = ((q_i+u_h).k_j + (q_i+v_h).P[i-j]) / sqrt(dk); softmax over the utterance's keys; ctx = s.v
  * qkv: [rows, 3*h*dk] (q|k|v), ptab: [2*pmax-1, h*dk] with row (pmax-1+p) = linear_pos(pe(p)).
  * Layers/Attention.py:159-198 (rel_shift :138-157 folded into the index i-j), :66-92.
- * tile_rows selects the implementation: 128 = matrix-core kernel (v_mfma_f32_32x32x2_f32, exact fp32 products),
- * 64 = VALU kernel (one lane per query). */
+ * Matrix-core kernel (v_mfma_f32_32x32x2_f32, exact fp32 products); tile_rows must be 128.  flags: 0 = the plain form (one
+ * accumulation order at every grid size), or TTS_ATT_KEY_SPLIT / TTS_ATT_KEY_SPLIT_ALWAYS. */
 int tts_relpos_attention(const float* qkv, int32_t ld_qkv, const float* ptab, int32_t pmax, const float* bias_u,
                          const float* bias_v, float* ctx, int32_t ld_ctx, int32_t heads, int32_t dk,
-                         const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, tts_stream_t stream);
+                         const TtsTile* tiles, int32_t n_tiles, int32_t tile_rows, int32_t flags, tts_stream_t stream);
 /* The same attention for the 16-bit configurations: the three contractions on v_mfma_f32_32x32x16_f16 (q + u, q + v, k, v, the
  * table and the probabilities rounded to fp16 - in the bf16 configuration too; fp32 scores, statistics and output).  Same
  * arguments; tile_rows must be 128. */
@@ -337,8 +344,12 @@ int tts_destroy(TtsHandle* h);
  * ims-toucan-prosody-variance_amd/native.py. */
 int tts_load_weights(TtsHandle* h, const char* name, const void* host_ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
 
-/* Upper bound of the workspace a batch of B utterances of at most Lmax phonemes / Tmax frames will claim (bytes). */
+/* Upper bound of the workspace a batch of B utterances of at most Lmax phonemes / Tmax frames will claim (bytes): the sum of what
+ * the stage entries reserve for such a batch (the same expressions), growth slack of the arenas included.  Weights, the position
+ * tables and the tile tables are not workspace. */
 int64_t tts_workspace_bytes(const TtsHandle* h, int32_t B, int32_t Lmax, int32_t Tmax);
+/* Bytes the handle's workspace arenas hold right now (after a batch: what that batch - and every larger one before it - claimed). */
+int64_t tts_workspace_claimed(const TtsHandle* h);
 
 /* text: packed phoneme features [sum L, 62]; utt_emb [B, 64] (NULL for the single-speaker variant); lang_ids [B] (NULL: no
  * language embedding); phone_lengths: host [B].  Starts a batch: later stages work on the handle's state. */
@@ -391,7 +402,7 @@ const char* tts_last_error(void);
 int tts_diag_queue_nonzero(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
-#define TTS_ABI_VERSION 13
+#define TTS_ABI_VERSION 14
 int tts_abi_version(void);
 
 #ifdef __cplusplus

@@ -434,10 +434,12 @@ class Emulator:
     def tts_relpos_attention_f16(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream):
         """fp16 rounding points as in relpos_attention_f16_kernel: q + u, q + v, k, v, the table -> fp16; the probabilities
         exp(s - max) -> fp16 before the product with v (the normaliser sums the unrounded ones)."""
-        return self.tts_relpos_attention(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream, f16=True)
+        return self.tts_relpos_attention(qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, 0, stream, f16=True)
 
-    def tts_relpos_attention(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, stream, f16=False):
+    def tts_relpos_attention(self, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx, heads, dk, tiles, n_tiles, tile_rows, flags, stream, f16=False):
+        """(flags: the key-split forms differ from the plain one in rounding order only - float64 here either way)"""
         self._count("relpos_attention")
+        assert tile_rows == 128 and 0 <= flags <= 3
         hd = heads * dk
         r16 = (lambda a: _round16(np.asarray(a, dtype=np.float32), True).astype(np.float64)) if f16 else (lambda a: a)
         P = r16(_mat(ptab, 2 * pmax - 1, hd, hd).astype(np.float64))

@@ -170,8 +170,18 @@ def ref_vocoder(kind, sd_np):
     return m, taps
 
 
-def main():
-    dump_phone_table()
+def gold_prosody(u, L):
+    """Seeded gold pitch / energy curves of the UtteranceCloner kind (UtteranceCloner.py:147-194): positive values on every
+    phoneme - also on unvoiced ones, silences and word boundaries, which the control loop (InferenceToucanTTS.py:214-222) must
+    zero - so the fixture exercises the zeroing of GOLD values and the variance scaling on top of them."""
+    p = 0.2 + 1.6 * fw.uniform01(f"utt{u}.gold_pitch", L, 5000 + u)
+    e = 0.1 + 2.0 * fw.uniform01(f"utt{u}.gold_energy", L, 6000 + u)
+    return p.astype(np.float32), e.astype(np.float32)
+
+
+def main(only=None):
+    if only is None:
+        dump_phone_table()
     from ims_toucan_prosody_variance_amd import synthetic as syn
 
     ac_sd = fw.acoustic_state_dict()
@@ -199,6 +209,9 @@ def main():
         ("L20_ctrl", 21, 20, None, dict(duration_scaling_factor=1.2, pitch_variance_scale=1.3, energy_variance_scale=0.7,
                                         pause_duration_scaling_factor=1.2), True),
         ("L20_gold_odd", 22, 20, "ragged", dict(pitch_variance_scale=0.7), True),
+        # the fork's namesake path: gold durations AND gold pitch / energy (InferenceToucanTTS.py:209-210) with every scale != 1
+        ("L20_gold_prosody", 23, 20, "ragged", dict(pitch_variance_scale=1.4, energy_variance_scale=0.6,
+                                                    pause_duration_scaling_factor=1.5, duration_scaling_factor=1.1), True),
         ("L128_gold5", 0, 128, "gold5", {}, False),
         ("R128", 100, 128, "ragged", {}, False),
         ("R97", 101, 97, "ragged", {}, False),
@@ -206,7 +219,12 @@ def main():
         ("R20", 103, 20, "ragged", {}, False),
     ]
     summary = {}
+    if only is not None:
+        with open(os.path.join(out_dir, "SUMMARY.json")) as f:
+            summary = json.load(f)
     for name, u, L, mode, ctrl, full in cases:
+        if only is not None and name not in only:
+            continue
         feats = syn.utterance_features(u, L)
         emb = syn.utterance_embedding(u)
         text = torch.from_numpy(feats)
@@ -218,6 +236,11 @@ def main():
         kw = dict(ctrl)
         if durs is not None:
             kw["durations"] = torch.from_numpy(durs)
+        gp = ge = None
+        if name == "L20_gold_prosody":
+            gp, ge = gold_prosody(u, L)
+            assert (feats[:, 61] == 0).any() and (feats[:, 16] == 1).any() and (feats[:, 21] == 1).any()  # unvoiced, silence, boundary
+            kw["pitch"], kw["energy"] = torch.from_numpy(gp), torch.from_numpy(ge)
         # frame count is only known after the duration stage: run once with a long noise buffer
         if durs is None:
             probe = orc_ac(text, e, syn.LANG_EN, run_postflow=False, **{k: v for k, v in kw.items()})
@@ -227,7 +250,10 @@ def main():
             T = int(probe["durations"].sum())
         z = torch.from_numpy(syn.postflow_noise(u, T))
         with torch.inference_mode():
-            mel_r, dur_r, pitch_r, energy_r = ref_ac(text, e, syn.LANG_EN, z, **kw)
+            # the reference writes its zeroing into the tensors it was handed (InferenceToucanTTS.py:216-222 index-assign into
+            # views of the gold arguments) and wants gold pitch / energy as [L, 1] (it transposes them at :230-231): hand it copies
+            rkw = {k: (v.clone().reshape(-1, 1) if k in ("pitch", "energy") else v.clone() if torch.is_tensor(v) else v) for k, v in kw.items()}
+            mel_r, dur_r, pitch_r, energy_r = ref_ac(text, e, syn.LANG_EN, z, **rkw)
         rt = dict(ref_ac.taps)
         ot = {}
         o = orc_ac(text, e, syn.LANG_EN, z_noise=z, taps=ot, **kw)
@@ -268,6 +294,8 @@ def main():
                  enc_out=rt["enc_out"].numpy())
         if durs is not None:
             g["gold_durations"] = durs
+        if gp is not None:
+            g["gold_pitch"], g["gold_energy"] = gp, ge
         if full:
             for k, v in rt.items():
                 g["tap_" + k] = v.numpy()
@@ -297,4 +325,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(only=sys.argv[1:] or None)  # e.g. `make_golden.py L20_gold_prosody`: add one case, leave the other fixtures as they are

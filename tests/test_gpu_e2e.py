@@ -51,13 +51,15 @@ def _check_mel(mel, g, name=""):
     assert err.mean() < 1e-4, f"{name}: mel L1 {err.mean():.3e}"
 
 
-@pytest.mark.parametrize("name", ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "L128_gold5"])
+@pytest.mark.parametrize("name", ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "L20_gold_prosody", "L128_gold5"])
 def test_acoustic_matches_reference_golden(acoustic, name):
     g = _gold(name)
     texts, embs, langs, zs = _inputs([g])
     kw = json.loads(str(g["ctrl"]))
     if "gold_durations" in g.files:
         kw["durations"] = [torch.from_numpy(g["gold_durations"])]
+    if "gold_pitch" in g.files:  # gold prosody overrides (InferenceToucanTTS.py:209-210; UtteranceCloner.py:163): zeroed and scaled like predictions
+        kw["pitch"], kw["energy"] = [torch.from_numpy(g["gold_pitch"])], [torch.from_numpy(g["gold_energy"])]
     taps = {}
     out = acoustic.forward(texts, embs, langs, z_noise=zs, taps=taps, **kw)
     assert np.array_equal(out["durations"][0].cpu().numpy(), g["durations"]), "durations must be bit exact"

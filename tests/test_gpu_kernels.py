@@ -116,27 +116,19 @@ SPLIT_K_CASES = [
     (384, 1536, 1, 1, capi.MODE_LINEAR, [128, 5]),
     (256, 256, 3, 1, capi.MODE_LINEAR, [70, 33, 1]),     # variance-predictor conv
     (80, 512, 5, 1, capi.MODE_LINEAR, [100]),            # PostNet input conv: cin 80 < cin_pad 96
-    (264, 128, 7, 3, capi.MODE_LINEAR, [64, 65]),        # 33 channel groups (not a multiple of the four wavefronts), halo 18
+    (272, 128, 7, 3, capi.MODE_LINEAR, [64, 65]),        # 17 channel groups (not a multiple of the four wavefronts), halo 18
+    (32, 64, 3, 1, capi.MODE_LINEAR, [50]),              # two channel groups per tap: fewer k-steps per tap than wavefronts
     (384, 384, 1, 1, capi.MODE_GLU, [128, 33]),
     (192, 256, 3, 1, capi.MODE_COUPLING, [44, 63]),
     (192, 576, 1, 1, capi.MODE_LINEAR, [128]),           # q/k/v projection: 192 products per output
-    (80, 384, 1, 1, capi.MODE_LINEAR, [320, 2]),         # the flow's input conv: 80 products, 10 channel groups of 8
+    (80, 384, 1, 1, capi.MODE_LINEAR, [320, 2]),         # the flow's input conv: 80 products, 5 channel groups
     (256, 80, 5, 1, capi.MODE_LINEAR, [640]),            # no small-batch form (packed width 96): row blocks cut out of 128-row tiles
     (256, 1, 1, 1, capi.MODE_LINEAR, [128, 9]),          # predictor output: one column of a 256 x 32 tile
     (192, 160, 1, 1, capi.MODE_COUPLING, [320]),         # coupling conv of the flow (half width 80, packed 96)
 ]
 
 
-@pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", SPLIT_K_CASES)
-@pytest.mark.parametrize("tile", [16, 32])
-def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, tile, monkeypatch):
-    """TTS_IO_SPLIT_K (fp32 convs of the acoustic model on grids of a few workgroups): against the emulator, and against the same
-    launch without the flag (rounding order only; the flag must really change the kernel: the results differ in the last bits).
-    tile: the 16 x 16 form (taken when the channels come in groups of 16 and the grid is tiny) or the 32 x 32 form alone."""
-    if tile == 32:
-        monkeypatch.setenv("TOUCAN_NO_SPLIT_K16", "1")
-    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
-    b = rnd(cout, seed=2, scale=0.1).numpy()
+def _split_k_run(w, b, cin, cout, k, dil, mode, lengths):
     dual = mode != capi.MODE_LINEAR
     co = cout // 2 if dual else cout
 
@@ -153,23 +145,75 @@ def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, tile, m
         ops.conv(cw, x, y[:, :co], rag, pre=capi.PRE_LRELU, pre_slope=0.1, act=capi.ACT_TANH, alpha=0.5, seqvec=sv, preadd=pre, res=res,
                  res_scale=0.25, aux=aux, accumulate=True, compute=capi.COMPUTE_F32)
         return y
+    return run
 
+
+@pytest.mark.parametrize("cin,cout,k,dil,mode,lengths", SPLIT_K_CASES)
+def test_conv1d_split_k_form(gpu, cpu, cin, cout, k, dil, mode, lengths, monkeypatch):
+    """The split-K form of the fp32 convs (TTS_IO_SPLIT_K: on grids of a few workgroups - these are; TTS_IO_SPLIT_K_ALWAYS: at any
+    size): against the emulator, and against the same launch without the flag (rounding order only; the flag must really change
+    the kernel: the results differ in the last bits).  The 16 x 16 and the 32 x 32 tile forms (TOUCAN_NO_SPLIT_K16 forces the
+    latter) sum in ONE order: bit-identical - which form the grid heuristics pick is a speed choice only."""
+    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
+    b = rnd(cout, seed=2, scale=0.1).numpy()
+    run = _split_k_run(w, b, cin, cout, k, dil, mode, lengths)
+    dev = lambda t: t.to("cuda:0").contiguous()
     gpu.small_tile_blocks = 1 << 30
     try:
-        gpu.split_k = True
+        gpu.split_k = 1
         g, c = both(gpu, cpu, run)
-        gpu.split_k = False
-        plain = run(gpu, lambda t: t.to("cuda:0").contiguous())
-        gpu.split_k = True
+        gpu.split_k = 2
+        always = run(gpu, dev)
+        monkeypatch.setenv("TOUCAN_NO_SPLIT_K16", "1")
+        g32 = run(gpu, dev)
+        monkeypatch.delenv("TOUCAN_NO_SPLIT_K16")
+        gpu.split_k = 0
+        plain = run(gpu, dev)
+        gpu.split_k = 1
         monkeypatch.setenv("TOUCAN_NO_SPLIT_K", "1")  # the escape hatch gives the other forms back, bit for bit
-        off = run(gpu, lambda t: t.to("cuda:0").contiguous())
+        off = run(gpu, dev)
     finally:
         gpu.small_tile_blocks = 1536
-        gpu.split_k = False
+        gpu.split_k = 0
     close(g, c, 2e-5)
     close(g, plain, 1e-5)
     assert not torch.equal(g, plain), "the split-K form did not run"
+    assert torch.equal(g, g32), "16 x 16 and 32 x 32 split-K tiles must sum in the same order"
+    assert torch.equal(g, always)
     assert torch.equal(off, plain)
+
+
+def test_conv1d_split_k_always_is_independent_of_the_grid(gpu, cpu):
+    """TTS_IO_SPLIT_K_ALWAYS (phoneme stages of the fp32 acoustic model): a 32-utterance batch - a grid far beyond the small-grid
+    limit, where TTS_IO_SPLIT_K falls back to the tiled form - gives every utterance the bits it gets alone."""
+    cin, cout, k = 192, 1536, 1
+    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
+    b = rnd(cout, seed=2, scale=0.1).numpy()
+    lengths = [128 - 3 * u for u in range(32)]
+    dev = lambda t: t.to("cuda:0").contiguous()
+    cw = packing.pack_conv(w, b, gpu.device, mode=capi.MODE_LINEAR)
+    rag = Ragged(lengths, gpu.device, align=2)
+    x = dev(rnd(rag.total_rows, cin, seed=3))
+
+    def conv(rg, xx):
+        y = dev(torch.zeros(rg.total_rows, cout))
+        gpu.conv(cw, xx, y, rg, act=capi.ACT_RELU, compute=capi.COMPUTE_F32)
+        return y
+    try:
+        gpu.split_k = 2
+        big = conv(rag, x)
+        for u in (0, 7, 31):
+            b0, n = rag.begins[u], rag.lengths[u]
+            one = conv(Ragged([n], gpu.device, align=2), x[b0:b0 + n].contiguous())
+            assert torch.equal(one[:n], big[b0:b0 + n]), u
+        gpu.split_k = 1
+        auto = conv(rag, x)
+        gpu.split_k = 0
+        plain = conv(rag, x)
+    finally:
+        gpu.split_k = 0
+    assert torch.equal(auto, plain) and not torch.equal(big, plain)
+    close(big, plain, 1e-5)
 
 
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 257]), (64, 11, 5, [300, 40]), (256, 7, 3, [130, 1, 2]), (128, 3, 5, [64, 8])])
@@ -306,8 +350,10 @@ def test_layernorm_cln_l2_groupnorm(gpu, cpu):
 
 
 @pytest.mark.parametrize("lengths", [[7], [64], [65, 128, 1], [640, 333], [129, 31, 33]])
-@pytest.mark.parametrize("tile_rows", [64, 128])
-def test_relpos_attention(gpu, cpu, lengths, tile_rows):
+@pytest.mark.parametrize("flags", [0, capi.ATT_KEY_SPLIT_ALWAYS])
+def test_relpos_attention(gpu, cpu, lengths, flags):
+    """The fp32 matrix-core kernel in its plain form and in the key-split form forced at every grid size (the encoder of the fp32
+    configuration), ragged batches incl. multi-tile utterances, against the emulator."""
     pmax = 700
 
     def run(ops, to):
@@ -315,28 +361,31 @@ def test_relpos_attention(gpu, cpu, lengths, tile_rows):
         qkv = to(rnd(rag.total_rows, 576, seed=1, scale=0.7))
         ptab = to(rnd(2 * pmax - 1, 192, seed=2, scale=0.5))
         ctx = to(torch.zeros(rag.total_rows, 192))
-        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, tile_rows)
+        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, 128, flags=flags)
     close(*both(gpu, cpu, run), tol=5e-5)
 
 
 @pytest.mark.parametrize("lengths", [[7], [640], [333, 129], [160, 33, 1]])
-def test_relpos_attention_key_split_form(gpu, cpu, lengths, monkeypatch):
-    """fp32 attention on grids of a few workgroups: the four wavefronts of a workgroup split the keys of one 32-query block and merge
-    their running (max, sum, output) in LDS.  Against the emulator, and against the plain form (TOUCAN_NO_ATTENTION_SPLIT): rounding
-    order only - and really another kernel (the last bits differ)."""
+def test_relpos_attention_key_split_form(gpu, cpu, lengths):
+    """fp32 attention, key-split form: the four wavefronts of a workgroup split the keys of one 32-query block and merge their
+    running (max, sum, output) in LDS.  The CALLER opts in (flags): TTS_ATT_KEY_SPLIT takes the form on small grids (these are),
+    TTS_ATT_KEY_SPLIT_ALWAYS at any size, 0 never.  Against the emulator, and against the plain form: rounding order only - and
+    really another kernel (the last bits differ); the two opt-in flags run the same kernel (bit-identical)."""
     pmax = 700
 
-    def run(ops, to):
+    def run(ops, to, flags=capi.ATT_KEY_SPLIT):
         rag = Ragged(lengths, ops.device, align=2)
         qkv = to(rnd(rag.total_rows, 576, seed=1, scale=0.7))
         ptab = to(rnd(2 * pmax - 1, 192, seed=2, scale=0.5))
         ctx = to(torch.zeros(rag.total_rows, 192))
-        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, 128)
+        return ops.attention(qkv, ptab, pmax, to(rnd(192, seed=3, scale=0.3)), to(rnd(192, seed=4, scale=0.3)), ctx, rag, 128, flags=flags)
     g, c = both(gpu, cpu, run)
-    monkeypatch.setenv("TOUCAN_NO_ATTENTION_SPLIT", "1")
-    plain = run(gpu, lambda t: t.to("cuda:0").contiguous())
+    dev = lambda t: t.to("cuda:0").contiguous()
+    plain = run(gpu, dev, flags=0)
+    always = run(gpu, dev, flags=capi.ATT_KEY_SPLIT_ALWAYS)
     close(g, c, tol=5e-5)
     close(g, plain, tol=1e-5)
+    assert torch.equal(g, always)
     if max(lengths) > 32:  # (with a single 32-key step the merge is exact: wavefront 0 holds everything)
         assert not torch.equal(g, plain), "the key-split form did not run"
     else:

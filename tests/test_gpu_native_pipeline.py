@@ -38,13 +38,15 @@ def pipes():
     return {k: native.NativePipeline(ac, sd, k, DEV) for k, sd in (("hifigan", fw.hifigan_state_dict()), ("bigvgan", fw.bigvgan_state_dict()))}
 
 
-@pytest.mark.parametrize("name", ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "L128_gold5"])
+@pytest.mark.parametrize("name", ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "L20_gold_prosody", "L128_gold5"])
 def test_stage_api_matches_reference_golden(pipes, name):
     g = _gold(name)
     texts, embs, langs, zs = _inputs([g])
     kw = json.loads(str(g["ctrl"]))
     if "gold_durations" in g.files:
         kw["durations"] = [torch.from_numpy(g["gold_durations"])]
+    if "gold_pitch" in g.files:  # gold prosody overrides (InferenceToucanTTS.py:209-210; UtteranceCloner.py:163): zeroed and scaled like predictions
+        kw["pitch"], kw["energy"] = [torch.from_numpy(g["gold_pitch"])], [torch.from_numpy(g["gold_energy"])]
     out = pipes["hifigan"].forward(texts, embs, langs, z_noise=zs, **kw)
     assert np.array_equal(out["durations"][0].cpu().numpy(), g["durations"]), "durations must be bit exact"
     np.testing.assert_allclose(out["pitch"][0].cpu().numpy(), g["pitch"], atol=5e-5)
@@ -159,6 +161,24 @@ def test_synthesize_batch_one_call_and_error_paths(pipes):
     assert lib.tts_encoder(h2, p(text), p(emb), p(lang), lens, B, st) != 0 and b"was not loaded" in lib.tts_last_error()
     assert lib.tts_destroy(h2) == 0
     assert pipe.workspace_bytes(32, 128, 640) > pipe.workspace_bytes(1, 128, 640) > 0
+
+
+@pytest.mark.parametrize("precision,kind", [("f32", "bigvgan"), ("bf16", "bigvgan"), ("f32", "hifigan")])
+def test_workspace_bound_covers_what_a_batch_claims(precision, kind):
+    """tts_workspace_bytes(B, Lmax, Tmax) is an upper bound of what the arenas really hold after a batch of that shape
+    (tts_workspace_claimed) - and not a wild one (within 2x for a ragged batch described by its maxima): a caller budgets HBM from it."""
+    voc_sd = fw.bigvgan_state_dict() if kind == "bigvgan" else fw.hifigan_state_dict()
+    pipe = native.NativePipeline(fw.acoustic_state_dict(), voc_sd, kind, DEV, precision=precision)
+    for names in (("R20",), ("R128", "R97", "R64", "R20")):
+        gs = [_gold(n) for n in names]
+        texts, embs, langs, zs = _inputs(gs)
+        durs = [torch.from_numpy(g["gold_durations"]) for g in gs]
+        pipe.forward(texts, embs, langs, durations=durs, z_noise=zs)
+        torch.cuda.synchronize()
+        B, Lmax, Tmax = len(gs), max(t.shape[0] for t in texts), max(int(d.sum()) for d in durs)
+        bound, claimed = pipe.workspace_bytes(B, Lmax, Tmax), pipe.workspace_claimed()
+        assert claimed > 0 and bound >= claimed, (names, bound, claimed)
+        assert bound < 2 * claimed + (256 << 20), (names, bound, claimed)
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])

@@ -13,7 +13,7 @@ from ims_toucan_prosody_variance_amd import fixture_weights as fw
 from oracle import toucan_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SMALL = ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "R20"]
+SMALL = ["L7_pred", "L20_pred", "L20_ctrl", "L20_gold_odd", "L20_gold_prosody", "R20"]
 
 
 @pytest.fixture(scope="module")
@@ -31,6 +31,8 @@ def _run(acoustic, g, taps=None):
     kw = json.loads(str(g["ctrl"]))
     if "gold_durations" in g:
         kw["durations"] = torch.from_numpy(g["gold_durations"])
+    if "gold_pitch" in g:  # gold prosody overrides (InferenceToucanTTS.py:209-210): still zeroed and variance-scaled
+        kw["pitch"], kw["energy"] = torch.from_numpy(g["gold_pitch"]), torch.from_numpy(g["gold_energy"])
     return acoustic(torch.from_numpy(g["text"]), torch.from_numpy(g["utt_emb"]), int(g["lang_id"]),
                     z_noise=torch.from_numpy(g["z"]), taps=taps, **kw)
 
@@ -52,6 +54,17 @@ def test_acoustic_oracle_matches_reference_golden(acoustic, name):
             np.testing.assert_allclose(taps[k[4:]].numpy(), g[k], atol=2e-5, err_msg=k)
         if k.startswith("tap_glow_z"):
             np.testing.assert_allclose(taps[k[4:]].numpy(), g[k], atol=1e-4, err_msg=k)
+
+
+def test_gold_prosody_golden_exercises_zeroing_and_scaling_of_gold_values():
+    """The fixture is not vacuous: gold pitch / energy are positive everywhere, the reference zeroed the unvoiced / non-phoneme
+    positions and moved the rest (variance scales 1.4 / 0.6), and pause + duration scaling changed the gold durations."""
+    g = np.load(os.path.join(GOLDEN, "L20_gold_prosody.npz"))
+    assert (g["gold_pitch"] > 0).all() and (g["gold_energy"] > 0).all()
+    unvoiced, non_phone = g["text"][:, 61] == 0, g["text"][:, 15] == 0
+    assert unvoiced.any() and non_phone.any() and (~unvoiced).any()
+    assert not np.allclose(g["pitch"][~unvoiced], g["gold_pitch"][~unvoiced]) and not np.allclose(g["energy"][~non_phone], g["gold_energy"][~non_phone])
+    assert not np.array_equal(g["durations"], g["gold_durations"]) and (g["durations"][g["text"][:, 21] == 1] == 0).all()
 
 
 def test_odd_frame_count_is_truncated_by_the_flow_squeeze(acoustic):

@@ -32,7 +32,7 @@ def main():
         y = torch.empty(rag.total_rows, cout // 2 if mode != capi.MODE_LINEAR else cout, device=dev)
         for comp, cname in ((capi.COMPUTE_F32, "f32"), (capi.COMPUTE_BF16, "bf16")):
             for split in ((False, True) if comp == capi.COMPUTE_F32 else (False,)):
-                ops.split_k = split  # fp32: also the split-K form the acoustic model opts into (TTS_IO_SPLIT_K)
+                ops.split_k = int(split)  # fp32: also the split-K form the acoustic model opts into (TTS_IO_SPLIT_K)
                 run = lambda: ops.conv(cw, x, y, rag, compute=comp)
                 for _ in range(3):
                     run()
