@@ -127,8 +127,8 @@ def committed_counters(kernel, algorithmic_bytes=None):
             continue
         if algorithmic_bytes is not None:
             # the counter pass ran the micro-benchmark, not this process: its launch must be the bench's launch (same rows x channels
-            # x 16-bit read + write), or the traffic figure would describe another shape
-            assert all(abs(r["algorithmic_bytes"] - algorithmic_bytes) <= 1e-6 * algorithmic_bytes for r in rows), \
+            # x 16-bit read + write; the bench's figure also counts the weights, < 0.1 %), or the traffic would describe another shape
+            assert all(abs(r["algorithmic_bytes"] - algorithmic_bytes) <= 2e-3 * algorithmic_bytes for r in rows), \
                 f"{path}: counter pass shape ({rows[0]['algorithmic_bytes']} B per launch) is not the bench's launch ({algorithmic_bytes} B)"
         traffic = sum(r["hbm_bytes_corrected"] for r in rows) / len(rows)
         valu = None
@@ -194,8 +194,8 @@ def verify_against_single_run(pipe, out, wav, packed, z_sq, scales, B, oracle=No
     one = dict(Ls=[L0], text=cut(packed["text"], L0), emb=cut(packed["emb"], 1), lang=cut(packed["lang"], 1), gp=cut(packed["gp"], L0),
                ge=cut(packed["ge"], L0), gd=cut(packed["gd"], L0))
     T0 = int(out["rag_frame"].lengths[0])
-    rs = Ragged([T0], pipe.device, align=2).halved()
-    o1 = pipe.forward(None, None, packed=one, z_sq=z_sq[: rs.total_rows].contiguous(), vocode=False, **scales)
+    rows_sq = Ragged([T0], pipe.device, align=2).total_rows // 2  # (utterance 0 starts at row 0 of the batch's squeezed noise too)
+    o1 = pipe.forward(None, None, packed=one, z_sq=z_sq[:rows_sq].contiguous(), vocode=False, **scales)
     w1, _ = pipe.vocode(o1["mel_packed"], o1["rag_mel"])
     torch.cuda.synchronize()
     n = int(out["rag_mel"].lengths[0])

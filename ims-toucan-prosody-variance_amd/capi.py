@@ -101,6 +101,7 @@ PROTOTYPES = {
     "tts_last_error": (C.c_char_p, []),
     "tts_abi_version": (C.c_int, []),
     "tts_diag_queue_nonzero": (C.c_int, []),
+    "tts_diag_queue_slots_used": (C.c_int, []),
     "tts_conv1d_tile_rows": (C.c_int, [_i, _i]),
     "tts_conv1d_n_tile": (C.c_int, [_i, _i]),
     "tts_conv1d_small_tile_rows": (C.c_int, [_i, _i, _i]),

@@ -23,6 +23,7 @@
 #include <mutex>
 #include <utility>
 #include <type_traits>
+#include <vector>
 #include <cstring>
 
 #include "common.h"
@@ -42,6 +43,9 @@ namespace tts {
 #define RB_C64_TPS 1        // taps per weight slab at C = 64 (tuning knob)
 #endif
 constexpr int RB_LEAD = 16;
+#ifndef RB_STAGGER_DEFAULT
+#define RB_STAGGER_DEFAULT 0   // (x 1 024 cycles; set from the measurement in DESIGN.md section 5)
+#endif
 
 // Workgroup barrier of this kernel: LDS traffic of the wavefront has landed (lgkmcnt), then s_barrier.  __syncthreads() also drains
 // every global load in flight (vmcnt(0)) - here that would be the next tile's image, the residual and the next weight slab, all
@@ -49,10 +53,20 @@ constexpr int RB_LEAD = 16;
 __device__ __forceinline__ void rb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Work queues of the persistent tile loop: one 16-word slot per launch in flight (zero when a launch starts; its last workgroup
-// leaves it zero again).  Launches take slots round-robin; two launches could only share a slot if RB_QUEUE_SLOTS launches
-// of this kernel were in flight on the device at once.
-constexpr int RB_QUEUE_SLOTS = 256;
+// leaves it zero again).  Two launches may share a slot only if they can never be in flight together, so a slot belongs to a
+// STREAM (launches of one stream run in order: launch_rb keeps a (device, stream) -> slot table), and every launch recorded into
+// a HIP graph gets a slot of its own for the life of the process (a replay may run on any stream, beside eager launches or other
+// graphs; the same graph never runs beside itself).  Slots are handed out once and never recycled: 4 MiB of device memory cover
+// 65 536 of them, i.e. that many streams plus captured launches per process and device.
+constexpr int RB_QUEUE_SLOTS = 1 << 16;
 __device__ unsigned int g_rb_queue[RB_QUEUE_SLOTS][16];
+// Arrival counters per CU (index: XCC_ID, then the shader-engine / shader-array / CU fields of HW_ID): the two workgroups a CU hosts
+// at C <= 64 learn from the PARITY of their arrival which of the two they are, and the second one starts a quarter of a tile
+// period late (`stagger`).  A tile is vector work (staging, snake), matrix work (conv), vector work (epilogue, snake), matrix work
+// (conv): two co-resident workgroups that start together stay in lockstep - both on the vector pipe, then both on the matrix pipe,
+// each time at half speed - while a quarter period apart one's convs run beside the other's snakes on every SIMD.  Speed only:
+// never reset (two consecutive arrivals differ in parity whatever the count), and a wrong guess costs nothing but the overlap.
+__device__ unsigned int g_rb_cu_arrivals[8 * 256];
 
 // Timing diagnostics (tools/build_variant.sh NAME -DRB_DIAG_CLOCK[=wave]): every phase boundary of the matrix-core-snake path is
 // stamped with s_memtime; one wavefront per workgroup stores its stamps into g_rb_trace, read back by
@@ -144,7 +158,7 @@ struct RbSlab {
 //       VALU form; the activation window then carries 6 raw rows in front and behind (the filters' reach) and is transformed in place
 template <int C, bool IOB, bool F16, bool MFIR>
 // (C = 32: with the prefetching snake two spill-free workgroups per CU beat three at the 80-register cap by ~10 %)
-__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d, const int queue_slot) {
+__global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 64 ? 4 : (C == 128 ? 2 : 1)))) void resblock_step_kernel(const TtsResblockDesc d, const int queue_slot, const int stagger) {
   constexpr int RB_M1 = RbCfg<C>::M1, RB_BM = RbCfg<C>::BM, RB_THREADS = RbCfg<C>::THREADS;
   constexpr int KC = RbCfg<C>::KC;        // channels per weight slab (all of them for C <= 128: one step per tap, act1(x) staged once)
   constexpr int XP = KC + 8;              // act1(x) window pitch (bf16 elements; 16-B aligned rows, odd number of 16-B slots)
@@ -240,6 +254,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   for (int k = 0; k < 12; ++k)
     f[k] = snake ? __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, d.filt[k]))) : 0.0f;  // (kept in scalar registers)
   if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);  // (in flight while the constants below are fetched)
+  unsigned int arrival = 0;
+  if (stagger > 0 && tid == 0) arrival = atomicAdd(&g_rb_cu_arrivals[(xcc << 8) | ((__builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4)) & 255)], 1u);  // HW_ID[15:8]
   if (tid < C / 4) reinterpret_cast<float4*>(cst_b1)[tid] = reinterpret_cast<const float4*>(d.b1)[tid];
   else if (tid < C / 2) reinterpret_cast<float4*>(cst_b2)[tid - C / 4] = reinterpret_cast<const float4*>(d.b2)[tid - C / 4];
   // (C = 128 has no 4 KB of LDS left at 11 taps x dilation 5, but registers to spare: there the table's 16 registers stay live)
@@ -337,9 +353,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     int first = tile_of_ticket(ticket_raw);
     if (first < 0) first = steal_tile();
     cst_ticket[0] = first;
+    cst_ticket[1] = (int)(arrival & 1u);
   }
   rb_barrier();
   int cur_tile = __builtin_amdgcn_readfirstlane(cst_ticket[0]);
+  if (stagger > 0 && __builtin_amdgcn_readfirstlane(cst_ticket[1]) != 0) {  // the CU's second workgroup: start `stagger` x 1 024 cycles late
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
   if (cur_tile < 0) {  // (more workgroups than tiles)
     retire(tid);
     return;
@@ -863,14 +883,32 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 // Diagnostic (tests/conftest.py calls it after every GPU test): words of the work-queue slots that are not zero once the device
 // is idle.  Every launch must leave its slot clean - a dirty slot would hand the launch that next draws it tickets that start
 // in the middle of a run.  Returns the count (0 = clean), negative on a HIP error.
+namespace tts {
+static std::mutex g_rb_slot_lock;
+static std::map<int, int> g_rb_slots_used;                             // device -> slots handed out so far
+static std::map<std::pair<int, hipStream_t>, int> g_rb_stream_slot;    // (device, stream) -> its slot
+}  // namespace tts
 extern "C" int tts_diag_queue_nonzero(void) {
-  static unsigned int host[tts::RB_QUEUE_SLOTS][16];
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tts::g_rb_queue), sizeof(host)) != hipSuccess) return -2;
+  static std::vector<unsigned int> host;
+  int dev = 0, used = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+  {
+    std::lock_guard<std::mutex> guard(tts::g_rb_slot_lock);
+    used = tts::g_rb_slots_used[dev];
+  }
+  if (used == 0) return 0;
+  host.resize((size_t)used * 16);
+  if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(tts::g_rb_queue), host.size() * sizeof(unsigned int)) != hipSuccess) return -2;
   int n = 0;
-  for (int s = 0; s < tts::RB_QUEUE_SLOTS; ++s)
-    for (int i = 0; i < 16; ++i) n += host[s][i] != 0;
+  for (unsigned int v : host) n += v != 0;
   return n;
+}
+// slots handed out on the current device so far (tests: a captured launch takes a fresh one, a stream keeps its own)
+extern "C" int tts_diag_queue_slots_used(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> guard(tts::g_rb_slot_lock);
+  return tts::g_rb_slots_used[dev];
 }
 namespace tts {
 
@@ -886,7 +924,22 @@ namespace tts {
 #undef load_slab
 #undef store_slab
 
-static std::atomic<unsigned int> g_rb_launches{0};  // launches of every instantiation so far: the work-queue slot of the next one
+// The work-queue slot of a launch on `st` (see g_rb_queue): the stream's own slot, or - while the stream is being captured into a
+// HIP graph - a fresh one that stays with the recorded kernel node.  -1: the pool is used up.
+static int rb_queue_slot(int dev, hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+  std::lock_guard<std::mutex> guard(g_rb_slot_lock);
+  int& used = g_rb_slots_used[dev];
+  if (!capturing) {
+    auto it = g_rb_stream_slot.find({dev, st});
+    if (it != g_rb_stream_slot.end()) return it->second;
+  }
+  if (used >= RB_QUEUE_SLOTS) return -1;
+  const int slot = used++;
+  if (!capturing) g_rb_stream_slot[{dev, st}] = slot;
+  return slot;
+}
 
 template <int C, bool IOB, bool F16, bool MFIR>
 static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
@@ -931,10 +984,15 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   if (fixed_per_cu > 0) per_cu = fixed_per_cu;
   const long resident = (long)cus * per_cu;
   const int grid = (int)(fixed_per_cu < 0 || d.n_tiles < resident ? d.n_tiles : resident);  // (TOUCAN_RB_WG_PER_CU=-1: one workgroup per tile)
-  // (ONE counter for every instantiation of this template: a function-local static would give each channel class its own, and
-  //  two classes launched on two streams would walk the slots in lockstep and share them)
-  const int queue_slot = (int)(g_rb_launches.fetch_add(1, std::memory_order_relaxed) % RB_QUEUE_SLOTS);
-  hipLaunchKernelGGL(k, dim3(grid), dim3(RB_THREADS), lds, st, d, queue_slot);
+  const int queue_slot = rb_queue_slot(dev, st);
+  if (queue_slot < 0) {
+    set_error("resblock_step: all %d work-queue slots of device %d are taken (streams + launches captured into HIP graphs)", RB_QUEUE_SLOTS, dev);
+    return TTS_E_LAUNCH;
+  }
+  // second workgroup of a CU (C <= 64: two per CU) starts late by this many units of 1 024 cycles - see g_rb_cu_arrivals
+  static const int stagger_env = std::getenv("TOUCAN_RB_STAGGER") ? std::atoi(std::getenv("TOUCAN_RB_STAGGER")) : -1;
+  const int stagger = (per_cu == 2 && grid == resident) ? (stagger_env >= 0 ? stagger_env : RB_STAGGER_DEFAULT) : 0;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(RB_THREADS), lds, st, d, queue_slot, stagger);
   return launch_status("resblock_step");
 }
 

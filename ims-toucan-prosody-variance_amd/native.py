@@ -241,8 +241,9 @@ class NativePipeline:
 
     def squeeze_noise(self, z_noise, frame_counts):
         """Per-utterance noise [80, T_u] -> the squeezed packed layout tts_postflow takes ([total_frames / 2, 160], 2-aligned begins)."""
-        rag_s = Ragged(frame_counts, self.device, align=2).halved()
-        z_sq = torch.zeros(rag_s.total_rows, 160, dtype=torch.float32, device=self.device)
+        rag_f = Ragged(frame_counts, self.device, align=2)
+        rag_s = rag_f.halved()
+        z_sq = torch.zeros(rag_f.total_rows // 2, 160, dtype=torch.float32, device=self.device)  # (incl. the row an odd last utterance leaves unused)
         for zu, b0, n in zip(z_noise, rag_s.begins, rag_s.lengths):
             z_sq[b0:b0 + n].copy_(torch.as_tensor(zu, dtype=torch.float32).t()[: 2 * n].reshape(n, 160))
         return z_sq

@@ -400,6 +400,10 @@ const char* tts_last_error(void);
  * tts_resblock_step launch draws its tiles from one 16-word slot and must leave it zero again).  0 = clean; negative = HIP error.
  * The test suite calls it after every GPU test. */
 int tts_diag_queue_nonzero(void);
+/* Work-queue slots handed out on the current device so far: one per stream that has launched tts_resblock_step, plus one per
+ * launch recorded into a HIP graph (a recorded launch keeps its slot for the life of the process; slots are never shared between
+ * launches that can be in flight together).  Tests only. */
+int tts_diag_queue_slots_used(void);
 /* Bumped whenever a struct layout or a prototype in this header changes; a binding must refuse a library that reports
  * another value (the descriptors are passed by layout, a stale build would read garbage). */
 #define TTS_ABI_VERSION 14

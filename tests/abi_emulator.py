@@ -128,6 +128,9 @@ class Emulator:
     def tts_diag_queue_nonzero(self):
         return 0  # (the emulator has no work queues)
 
+    def tts_diag_queue_slots_used(self):
+        return 0
+
     def tts_conv1d_tile_rows(self, cout, mode):
         return self._reallib().tts_conv1d_tile_rows(cout, mode)
 

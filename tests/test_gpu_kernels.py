@@ -719,3 +719,60 @@ def test_concurrent_fused_residual_steps_do_not_share_work_queues(gpu):
         for y, want, rag in zip(outs, alone, (cs[3] for cs in cases)):
             rows = torch.cat([torch.arange(b0, b0 + n) for b0, n in zip(rag.begins, rag.lengths)]).to(dev)
             assert torch.equal(y[rows], want[rows])
+
+
+def test_graph_replay_beside_eager_residual_steps_on_another_stream(gpu):
+    """Work-queue slots cannot alias between launches that may be in flight together: a slot belongs to a stream (eager launches of
+    one stream run in order), and every launch recorded into a HIP graph owns a slot of its own.  A graph of three fused residual
+    steps is replayed on one stream while the same steps run eagerly on another - also on the very stream the graph was captured
+    on - several times over; every output is bit for bit what the launches give alone.  (With slots chosen round-robin at launch
+    time and baked into the graph - the previous scheme - a replay could meet an eager launch on its slot.)"""
+    dev = "cuda:0"
+    lib = capi.lib()
+    filt = torch.from_numpy(packing.kaiser_sinc_filter12()).to(dev)
+    c, k, dil, lengths = 64, 7, 3, [9000, 4000, 333]
+    w1 = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
+    w2 = rnd(c, c, k, seed=11, scale=1.0 / np.sqrt(c * k)).numpy()
+    b = rnd(c, seed=21, scale=0.1).numpy()
+    rag = Ragged(lengths, gpu.device, align=2)
+    c1 = packing.pack_conv(w1, b, gpu.device, dil=dil, bf16="f16")
+    c2 = packing.pack_conv(w2, b, gpu.device, dil=1, bf16="f16")
+    x = rnd(rag.total_rows, c, seed=31).to(dev).to(torch.float16)
+    sn = (rnd(c, seed=41, scale=0.3).to(dev), rnd(c, seed=51, scale=0.3).to(dev))
+    rows = torch.cat([torch.arange(b0, b0 + n) for b0, n in zip(rag.begins, rag.lengths)]).to(dev)
+
+    def chain(bufs):  # three dependent steps: x -> bufs[0] -> bufs[1] -> bufs[2]
+        src = x
+        for y in bufs:
+            gpu.resblock_step(c1, c2, src, y, rag, capi.PRE_SNAKE, 0.1, sn, sn, filt)
+            src = y
+    want = [torch.zeros_like(x) for _ in range(3)]
+    chain(want)
+    torch.cuda.synchronize()
+    s_cap, s_other = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    g_out = [torch.zeros_like(x) for _ in range(3)]
+    used0 = lib.tts_diag_queue_slots_used()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s_cap):
+        chain(g_out)  # (the capture stream's own eager slot exists before the capture)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, stream=s_cap):
+            chain(g_out)
+    torch.cuda.synchronize()
+    assert lib.tts_diag_queue_slots_used() == used0 + 1 + 3, "one slot for the stream, one per recorded launch"
+    for eager_stream in (s_other, s_cap):
+        replay_stream = s_other if eager_stream is s_cap else s_cap
+        for _ in range(4):
+            for t in g_out:
+                t.zero_()
+            e_out = [torch.zeros_like(x) for _ in range(3)]
+            torch.cuda.synchronize()
+            with torch.cuda.stream(replay_stream):
+                graph.replay()
+            with torch.cuda.stream(eager_stream):
+                chain(e_out)
+                chain(e_out)
+            torch.cuda.synchronize()
+            for got_g, got_e, w in zip(g_out, e_out, want):
+                assert torch.equal(got_g[rows], w[rows]) and torch.equal(got_e[rows], w[rows])
+    assert lib.tts_diag_queue_slots_used() == used0 + 1 + 3 + 1, "eager launches of a stream reuse its slot"

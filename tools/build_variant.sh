@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 P=ims-toucan-prosody-variance_amd
 mkdir -p $P/build/variants/$name
-for s in conv1d resblock rowops attention attention_mfma sequence_ops capi pipeline style wavenet ffn; do
+for s in conv1d resblock rowops attention_mfma sequence_ops capi pipeline style wavenet ffn; do
   extra="$*"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -c $P/csrc/$s.hip -o $P/build/variants/$name/$s.o 2>/dev/null &
 done
