@@ -43,6 +43,15 @@ namespace tts {
 #define RB_C64_TPS 1        // taps per weight slab at C = 64 (tuning knob)
 #endif
 constexpr int RB_LEAD = 16;
+// Wave priority inside the conv phases (matrix work) relative to every other phase (vector work): a co-resident workgroup's vector
+// instructions then fill the issue slots a matrix instruction leaves free instead of delaying it (A/B knob; 0 = no priority change)
+#ifndef RB_PRIO_CONV
+#define RB_PRIO_CONV 0
+#endif
+#ifndef RB_PRIO_BASE
+#define RB_PRIO_BASE 0
+#endif
+#define RB_SETPRIO(p_) do { if (RB_PRIO_CONV != RB_PRIO_BASE) __builtin_amdgcn_s_setprio(p_); } while (0)
 #ifndef RB_STAGGER_DEFAULT
 #define RB_STAGGER_DEFAULT 0   // (x 1 024 cycles; set from the measurement in DESIGN.md section 5)
 #endif
@@ -109,6 +118,10 @@ struct RbCfg {
   // wave: C = 32 moves a whole conv per step (<= 22 KB; lrelu step -8..-22 %, snake step -3..-11 % measured).  Two taps per
   // step at C = 64 measured neutral and doubled the scalar-register spills, so it keeps one
   static constexpr int TPS = C == 32 ? 11 : (C == 64 ? RB_C64_TPS : 1);
+  // weight slabs through a three-slot LDS-DMA ring (see the kernel): slabs per tap
+  static constexpr bool DMA = C == 64 || C == 128;
+  static constexpr int SPLIT = C == 128 ? 2 : 1;
+  static constexpr int ring_elems(int taps) { return DMA ? 3 * (KC / SPLIT) * C : 2 * (taps < TPS ? taps : TPS) * KC * C; }
 };
 
 // register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
@@ -151,6 +164,40 @@ struct RbSlab {
   }
 };
 
+// One tap of a transposed conv for one wavefront: acc[j] (32 output channels x 32 frames) += W_tap[32 j .., :] . act[frames + tap, :].
+// ap: this lane's activation row at the tap's offset (+ 8 lk), bp: this lane's weight row of the slab (+ lk C 8).  All fragment
+// reads of a group of k-slices are issued BEFORE the group's first MFMA (the compiler's own schedule waited for LDS four times per
+// tap - read two fragments, wait, two MFMAs ... - so a tap cost ~1.5 k cycles for 256 cycles of matrix work per wavefront).
+struct RbNoop {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_reads(): called once, behind the first group's fragment reads and in front of its MFMAs (the DMA ring issues the next weight
+// slab there: in front of the reads the compiler drains LDS before it lets them go)
+template <int C, int KS, int TN, bool F16, class AfterReads = RbNoop>
+__device__ __forceinline__ void rb_conv_tap(const unsigned short* ap, const unsigned short* bp, f32x16 (&acc)[TN], AfterReads after_reads = AfterReads()) {
+  constexpr int GMAX = 48 / ((1 + TN) * 4);  // at most 48 fragment registers in flight
+  constexpr int G = GMAX >= KS ? KS : (GMAX >= 4 ? 4 : (GMAX >= 2 ? 2 : 1));  // k-slices read together (a divisor of KS = 2, 4, 8)
+#pragma unroll
+  for (int g0 = 0; g0 < KS; g0 += G) {
+    bf16x8 a[G], b[G][TN];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      a[g] = *reinterpret_cast<const bf16x8*>(ap + (g0 + g) * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[g][j] = *reinterpret_cast<const bf16x8*>(bp + ((size_t)(g0 + g) * 2 * C + j * 32) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (g0 == 0) {
+      after_reads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = mfma16<F16>(b[g][j], a[g], acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
+  }
+}
+
 // waves per SIMD the register allocation must leave room for: 2 / 2 / 1 / 1 workgroups per CU (C = 32 / 64 / 128 / 256)
 // IOB: x / y are bf16 tensors in HBM (compile-time so that each instantiation carries one I/O path only)
 // F16: the 16-bit element format everywhere in the kernel (LDS tiles, weights, 16-bit x / y) is IEEE fp16 instead of bf16
@@ -170,6 +217,17 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   constexpr int SLAB = TPS * TAPW;        // one weight slab
   constexpr int UNITS = SLAB / 8;         // 16-byte units
   constexpr int UPT = (UNITS + RB_THREADS - 1) / RB_THREADS;
+  // Weight slabs, C = 64 / 128 (DMA): a ring of THREE LDS slots filled by direct global -> LDS loads (global_load_lds_dwordx4: no
+  // staging registers, no ds_write, nothing to wait for at the end of a step), two slabs in flight, counted vmcnt, one raw barrier
+  // per step.  A slab is one tap at C = 64 (8 KB) and half a tap (64 of the 128 input channels, 16 KB) at C = 128: the ring is
+  // 24 / 48 KB.  Steps run on across tiles (the ring position is carried), so the first two slabs of the next tile are in flight
+  // behind the last conv2 steps.  C = 32 (both convs resident in LDS) and C = 256 keep the register-staged two-slot form.
+  constexpr bool DMA = RbCfg<C>::DMA;
+  constexpr int SPLIT = RbCfg<C>::SPLIT;            // slabs per tap
+  constexpr int SLAB_K = KC / SPLIT;                // input channels per DMA slab
+  constexpr int DMA_ELEMS = SLAB_K * C;             // 16-bit elements per ring slot
+  constexpr int DMA_PW = DMA ? DMA_ELEMS / 8 / RB_THREADS : 1;  // global_load_lds instructions per wavefront and slab
+  static_assert(!DMA || (DMA_ELEMS / 8) % RB_THREADS == 0, "a DMA slab is whole rounds of the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
   // Persistent workgroups over a work queue: the grid is one residency's worth of workgroups, each takes tile after tile until
@@ -222,6 +280,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   };
 
+  RB_SETPRIO(RB_PRIO_BASE);
   const int h1 = (d.taps - 1) / 2 * d.dil, h2 = (d.taps - 1) / 2;
   const int win_rows = RB_M1 + 2 * h1;
   static_assert(!MFIR || (C <= 128 && KC == C), "the matrix-core snake needs whole-C slabs (one window pitch for xa and t1)");
@@ -237,13 +296,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (prologue only: the tile loop re-derives them, see there)
   const bool snake = d.act == TTS_PRE_SNAKE;
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
-  const int spc = (d.taps + TPS - 1) / TPS;  // slab steps per channel chunk
+  const int spc = DMA ? d.taps * SPLIT : (d.taps + TPS - 1) / TPS;  // slab steps per channel chunk
   const int steps1 = NCH * spc, total_steps = 2 * steps1;
-  const int slab_alloc = (d.taps < TPS ? d.taps : TPS) * TAPW;  // LDS elements per slab buffer
+  const int slab_alloc = DMA ? DMA_ELEMS : (d.taps < TPS ? d.taps : TPS) * TAPW;  // LDS elements per slab buffer
 
   // constants every phase would otherwise fetch from global memory with the latency exposed (both biases, and the FIR operand
   // table of the matrix-core snake, which both sweeps load): copied into LDS once, visible after the staging barrier
-  float* cst_b1 = reinterpret_cast<float*>(ws + (size_t)2 * slab_alloc);    // [C]
+  float* cst_b1 = reinterpret_cast<float*>(ws + (size_t)(DMA ? 3 : 2) * slab_alloc);    // [C]
   float* cst_b2 = cst_b1 + C;                                               // [C]
   float* cst_snk = cst_b2 + C;                                              // [4][C]: e^a1 / 2 pi, 1 / (e^b1 + 1e-9), same for the second snake (FIR_LDS)
   uint4* cst_fir = reinterpret_cast<uint4*>(cst_snk + (MFIR && C < 128 ? 4 * C : 0));  // [256] (FIR_LDS && snake)
@@ -287,6 +346,34 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
 #define load_slab(step_) wreg.load(slab_src(step_), tid, slab_units(step_))
 #define store_slab(buf_) wreg.store(ws + (size_t)(buf_) * slab_alloc, tid)
 #endif
+  // DMA ring: slab `step` of a tile (conv1's slabs first, then conv2's; tap-major, the input-channel halves of a tap in order) into
+  // ring slot `slot`: thread t moves the 16-byte units t, t + THREADS, ... (a wavefront's 64 units are contiguous: 1 KB per instruction)
+  auto dma_issue = [&](int step, int slot, int tid_) __attribute__((always_inline)) {
+    if constexpr (DMA) {
+      const bool second = step >= steps1;
+      const int sidx = second ? step - steps1 : step;
+      const int tap = sidx / SPLIT, half = sidx % SPLIT;
+      const unsigned short* W = reinterpret_cast<const unsigned short*>(second ? d.w2 : d.w1);
+      const unsigned short* src = W + ((size_t)tap * (C / 8) + half * (SLAB_K / 8)) * C * 8;
+      unsigned short* dst = ws + (size_t)slot * DMA_ELEMS;
+      const int wv = __builtin_amdgcn_readfirstlane(tid_ >> 6), ln = tid_ & 63;
+#pragma unroll
+      for (int q = 0; q < DMA_PW; ++q) {
+        const int u0 = q * RB_THREADS + wv * 64;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(u0 + ln) * 8),
+                                         (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 8), 16, 0, 0);
+      }
+    }
+  };
+  // start of a step: this wavefront's part of the step's slab has landed (everything but the newest `keep` vector-memory operations
+  // is done: the next slab's DMA_PW loads - issued one step ago - are the youngest, plus whatever the previous step issued behind
+  // them), its LDS traffic is done, then the barrier: every wavefront's part has landed and nobody still reads the slot the next
+  // DMA overwrites
+  auto dma_step_barrier = [&](auto keep) __attribute__((always_inline)) {
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(keep)::value) : "memory");
+    rb_barrier();
+  };
+  int ring_pos = 0;  // ring slot of the current step (carried across tiles)
 #ifdef RB_DIAG_CLOCK
   unsigned long long stamp[10], phase_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -386,8 +473,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
   };
 
-  load_slab(0);
-  store_slab(0);
+  if constexpr (DMA) {
+    dma_issue(0, 0, tid);
+    dma_issue(1, 1, tid);
+  } else {
+    load_slab(0);
+    store_slab(0);
+  }
   // Two slab steps in all (C = 32: a whole conv per slab) = both convs' weights fit the ring: after the first tile of this
   // workgroup they are simply there - no loads, no staging stores, no waits for them in any later tile.
   const bool weights_resident = total_steps == 2;
@@ -582,6 +674,21 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       if (next_resolved < 0 && tid == 0) next_resolved = steal_tile();  // (rare: the end of this XCD's run)
       next_entry = *reinterpret_cast<const int4*>(d.tiles + (next_resolved >= 0 ? next_resolved : cur_tile));
     }
+    RB_SETPRIO(RB_PRIO_CONV);
+    if constexpr (DMA) {
+      for (int tap = 0; tap < d.taps; ++tap) {
+#pragma unroll
+        for (int half = 0; half < SPLIT; ++half, ++step) {
+          dma_step_barrier(std::integral_constant<int, DMA_PW>{});
+          int nxt = step + 2;  // (wraps into the next tile's first slabs; issued even without a next tile - drained before the kernel ends)
+          nxt = nxt >= total_steps ? nxt - total_steps : nxt;
+          const unsigned short* wb = ws + (size_t)ring_pos * DMA_ELEMS;
+          rb_conv_tap<C, SLAB_K / 16, TN, F16>(xa + (wave * 32 + lrow + tap * d.dil) * XP + half * SLAB_K + lk * 8, wb + (lk * C + lrow) * 8, acc,
+                                               [&]() __attribute__((always_inline)) { dma_issue(nxt, ring_pos >= 1 ? ring_pos - 1 : 2, tid); });
+          ring_pos = ring_pos == 2 ? 0 : ring_pos + 1;
+        }
+      }
+    } else {
     for (int tap0 = 0; tap0 < d.taps; tap0 += TPS, ++step) {
       rb_barrier();
       const bool restage = !weights_resident || first_tile;
@@ -590,18 +697,12 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
       for (int tt = 0; tt < nt; ++tt) {
         const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
         const int tap = tap0 + tt;
-#pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(xa + (wave * 32 + lrow + tap * d.dil) * XP + ks * 16 + lk * 8);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-            acc[j] = mfma16<F16>(b, a, acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
-          }
-        }
+        rb_conv_tap<C, KC / 16, TN, F16>(xa + (wave * 32 + lrow + tap * d.dil) * XP + lk * 8, wb + (lk * C + lrow) * 8, acc);
       }
       if (restage) store_slab((step + 1) & 1);
     }
+    }
+    RB_SETPRIO(RB_PRIO_BASE);
   }
 
   if (tid == 0) {  // (read by everyone behind the next barriers)
@@ -749,44 +850,70 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   uint2 xres[PREFETCH_RES ? TN : 1][4];
   // (the first step is peeled - not a flag inside the loop: a value defined on one side of a branch only is what the register
   // allocator spills first; for the same reason every wavefront fetches a residual, also the one without output rows)
+  auto conv2_prefetch = [&]() __attribute__((always_inline)) {
+    if constexpr (PREFETCH_RES) {
+      int row = tile.row0 + (wave < RB_BM / 32 ? wave : 0) * 32 + lrow;
+      row = row < tile.seq_end ? row : tile.seq_end - 1;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) xres[j][rq] = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + j * 32 + 8 * rq + 4 * lk);
+    }
+    if (XPF && snake && has_next) stage_issue(tile_next, tid);  // the next tile's image: in flight while conv2 and the epilogue run
+  };
   auto conv2_step = [&](auto first, int ch, int tap0) __attribute__((always_inline)) {
     rb_barrier();
     // (after the last step the ring's buffer 0 is free again: the next tile's first slab goes there)
     const bool more = (step + 1 < total_steps || has_next) && !weights_resident;  // (resident: conv2's slab came with the first tile's conv1)
     if (more) load_slab(step + 1 < total_steps ? step + 1 : 0);
-    if constexpr (decltype(first)::value) {
-      if constexpr (PREFETCH_RES) {
-        int row = tile.row0 + (wave < RB_BM / 32 ? wave : 0) * 32 + lrow;
-        row = row < tile.seq_end ? row : tile.seq_end - 1;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int rq = 0; rq < 4; ++rq) xres[j][rq] = *reinterpret_cast<const uint2*>(xh + (size_t)row * d.ldx + j * 32 + 8 * rq + 4 * lk);
-      }
-      if (XPF && snake && has_next) stage_issue(tile_next, tid);  // the next tile's image: in flight while conv2 and the epilogue run
-    }
+    if constexpr (decltype(first)::value) conv2_prefetch();
     if (wave < RB_BM / 32) {
       const int nt = d.taps - tap0 < TPS ? d.taps - tap0 : TPS;
       for (int tt = 0; tt < nt; ++tt) {
         const unsigned short* wb = ws + (size_t)(step & 1) * slab_alloc + tt * TAPW;
         const int tap = tap0 + tt;
-#pragma unroll
-        for (int ks = 0; ks < KC / 16; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + ks * 16 + lk * 8);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + ((ks * 2 + lk) * C + j * 32 + lrow) * 8);
-            acc[j] = mfma16<F16>(b, a, acc[j]);  // transposed product: accumulator row = output channel, column (lane) = frame
-          }
-        }
+        rb_conv_tap<C, KC / 16, TN, F16>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + ch * KC + lk * 8, wb + (lk * C + lrow) * 8, acc);
       }
     }
     if (more) store_slab((step + 1) & 1);
     ++step;
   };
+  // DMA form of a conv2 step: slab (tap, half).  keep: vector-memory operations that may stay in flight at the step's barrier
+  auto conv2_step_dma = [&](auto first, auto keep, int tap, int half) __attribute__((always_inline)) {
+    dma_step_barrier(keep);
+    int nxt = step + 2;
+    nxt = nxt >= total_steps ? nxt - total_steps : nxt;
+    // (every wavefront - also the one without output rows - issues its part of the slab load; the residual and next-image loads go
+    // behind it: the next barrier lets those stay in flight)
+    auto issue = [&]() __attribute__((always_inline)) {
+      dma_issue(nxt, ring_pos >= 1 ? ring_pos - 1 : 2, tid);
+      if constexpr (decltype(first)::value) conv2_prefetch();
+    };
+    if (wave < RB_BM / 32) {
+      const unsigned short* wb = ws + (size_t)ring_pos * DMA_ELEMS;
+      rb_conv_tap<C, SLAB_K / 16, TN, F16>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + half * SLAB_K + lk * 8, wb + (lk * C + lrow) * 8, acc, issue);
+    } else {
+      issue();
+    }
+    ring_pos = ring_pos == 2 ? 0 : ring_pos + 1;
+    ++step;
+  };
+  RB_SETPRIO(RB_PRIO_CONV);
+  if constexpr (DMA) {
+    constexpr int KEEP1 = DMA_PW + (PREFETCH_RES ? TN * 4 : 0);  // the step behind the peeled one: the residual loads may stay in flight
+    conv2_step_dma(std::true_type{}, std::integral_constant<int, DMA_PW>{}, 0, 0);
+    if constexpr (SPLIT == 2) conv2_step_dma(std::false_type{}, std::integral_constant<int, KEEP1>{}, 0, 1);
+    for (int tap = 1; tap < d.taps; ++tap) {
+      if (SPLIT == 1 && tap == 1) conv2_step_dma(std::false_type{}, std::integral_constant<int, KEEP1>{}, tap, 0);
+      else conv2_step_dma(std::false_type{}, std::integral_constant<int, DMA_PW>{}, tap, 0);
+      if constexpr (SPLIT == 2) conv2_step_dma(std::false_type{}, std::integral_constant<int, DMA_PW>{}, tap, 1);
+    }
+  } else {
   conv2_step(std::true_type{}, 0, 0);
   for (int ch = 0; ch < NCH; ++ch)
     for (int tap0 = ch == 0 ? TPS : 0; tap0 < d.taps; tap0 += TPS) conv2_step(std::false_type{}, ch, tap0);
+  }
+  RB_SETPRIO(RB_PRIO_BASE);
 
   if (has_next) rb_barrier();  // every wavefront is done reading t1 and the slab ring: the next tile's image may overwrite them
   if constexpr (L2PF) {
@@ -864,6 +991,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   cur_tile = next_tile;
   }  // tiles of this workgroup
 #undef RB_LANE_IDS
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two slabs requested past the last tile land before the LDS is released
   retire(tid_prologue);
 #ifdef RB_DIAG_CLOCK
   if (MFIR && snake && tid == 64 * (RB_DIAG_CLOCK + 0)) {
@@ -947,8 +1075,7 @@ static int launch_rb(const TtsResblockDesc& d, hipStream_t st) {
   const int h1 = (d.taps - 1) / 2 * d.dil;
   const int img_rows = MFIR ? RbCfg<C>::img_rows(h1) : RbCfg<C>::win_alloc(h1);
   const size_t xa = (((size_t)img_rows * (KC + 8)) + 7) & ~(size_t)7, t1 = (size_t)(RB_M1 + (MFIR ? 12 : 0)) * (C + 8);
-  const int slab_taps = d.taps < RbCfg<C>::TPS ? d.taps : RbCfg<C>::TPS;
-  size_t lds = ((xa > t1 ? xa : t1) + (size_t)2 * slab_taps * KC * C) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + 32;
+  size_t lds = ((xa > t1 ? xa : t1) + (size_t)RbCfg<C>::ring_elems(d.taps)) * 2 + (size_t)2 * C * 4 + (MFIR && C < 128 ? 4096 + 4 * C * 4 : 0) + 32;
   TTS_CHECK_ARG(lds <= 160 * 1024, "resblock_step: LDS %zu B exceeds 160 KiB", lds);
   auto k = resblock_step_kernel<C, IOB, F16, MFIR>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised

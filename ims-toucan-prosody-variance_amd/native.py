@@ -332,9 +332,18 @@ class NativePipeline:
                     out[key].record_stream(caller)
                 return out
 
-            for kw in batches:
+            for kw in batches:  # (may be a generator that builds a batch's device tensors on the caller's stream while we iterate)
                 kw = dict(kw)
                 kw["vocode"] = False
+                s_ac.wait_stream(caller)  # everything the caller enqueued for this batch so far is ordered in front of its acoustic pass
+                for v in kw.values():     # the inputs are read on s_ac: the allocator must not hand their memory out before that
+                    for t in (v if isinstance(v, (list, tuple)) else [v]):
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(s_ac)
+                    if isinstance(v, dict):
+                        for t in v.values():
+                            if torch.is_tensor(t) and t.is_cuda:
+                                t.record_stream(s_ac)
                 with torch.cuda.stream(s_ac):
                     out = self.forward(**kw)
                     mel_ready = torch.cuda.Event()
