@@ -5,18 +5,21 @@
 // intermediate tensors (act1(x), conv1 output, act2 of it) exist only in LDS, so HBM sees one read of x (plus
 // its halo) and one write of y instead of nine full-tensor passes.
 //
-// Decomposition (512 threads = 8 wavefronts, one utterance per workgroup via the tile table):
+// Decomposition (512 threads = 8 wavefronts; persistent workgroups that draw 224-row tiles of ONE utterance each from a
+// work queue, see below):
 //   * output tile: BM = 224 rows; conv1 is evaluated on M1 = 256 rows (BM + 16 each side: conv2's halo <= 5 and the
 //     anti-alias filter's halo 6), wave w owns rows 32w..32w+31 and all C columns (C/32 accumulators of 32x32).
-//   * act1(x) window (M1 + 2*h1 rows, h1 = (k-1)/2*dil, all C channels) is staged once as bf16; the anti-aliased snake
-//     is computed in registers while staging (snake.h), LeakyReLU element-wise.
-//   * conv1 accumulators (+bias) go to LDS as bf16 (t1, M1 x C); the second activation runs in place on t1
-//     (snake: every item first computes its 8 outputs into registers, barrier, then overwrites).
-//   * conv2 (dilation 1) reads its A operand straight from t1; waves 0..6 own the 224 output rows.
-//   * weight slabs of both convs stream through one double-buffered LDS ring with register prefetch.
-//   * epilogue: + bias2, alpha, + res_scale * x (re-read from global, L2-resident), optional accumulate, fp32 store.
+//   * the raw x window (M1 + 2*h1 + 12 rows, h1 = (k-1)/2*dil, all C channels) is staged once as fp16; the anti-aliased snake
+//     runs in place on it with both FIR filters on the matrix cores (snake_mfma.h; LeakyReLU: element-wise while staging).
+//   * both convs run TRANSPOSED (weights are the MFMA A operand): the accumulator has the output channel in the registers and
+//     the frame on the lane.  conv1's result (+ bias) goes to LDS as 8-byte channel quadruples (t1, overlaying the window),
+//     the second activation runs in place on t1, conv2 (dilation 1) reads it; waves 0..6 own the 224 output rows.
+//   * weight slabs: C = 64 / 128 through a three-slot LDS ring filled by global_load_lds (two slabs in flight, counted vmcnt,
+//     one raw barrier per tap); C = 32 keeps both convs' weights resident in LDS; C = 256 a register-staged two-slot ring.
+//   * epilogue in registers: + bias2, alpha, + res_scale * x (the residual pieces are fetched during conv2), optional
+//     accumulate, 8 / 16-byte row pieces straight from the accumulators - no LDS round trip, no barrier.
 // Rows outside the utterance are zero after each activation (the reference zero-pads every conv per utterance).
-// bf16 MFMA (v_mfma_f32_32x32x16_bf16) with fp32 accumulation; C in {32, 64, 128}.
+// 16-bit MFMA (v_mfma_f32_32x32x16_bf16 / _f16) with fp32 accumulation; C in {32, 64, 128, 256}.
 #include <atomic>
 #include <cstdlib>
 #include <map>

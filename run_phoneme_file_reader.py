@@ -2,10 +2,9 @@
 :19-41 the_raven, :44-51 main) on the MI355X-native ToucanTTSInterface, driven by phoneme strings.
 
 Same functions, same arguments, same output file (audios/the_raven_<version>.wav, 24 kHz, 10 600 samples of silence around
-every sentence).  The reference hands raw text to espeak-ng; offline there is no phonemizer, so the fourteen lines of the poem
-are carried here as phoneme strings as well (IPA, General American, the symbol set of the articulatory table) and
-``read_texts(..., input_is_phones=True)`` is what ``the_raven`` calls unless a phonemizer is importable.  With `phonemizer`
-installed the plain-text lines go through ``ToucanTTSInterface``'s text front end exactly as in the reference.
+every sentence).  The reference hands raw text to espeak-ng; this repository has no grapheme-to-phoneme step (raw text raises
+in ``ToucanTTSInterface``), so the fourteen lines of the poem are carried here as phoneme strings (IPA, General American, the
+symbol set of the articulatory table) and ``the_raven`` calls ``read_texts(..., input_is_phones=True)``.
 
     python run_phoneme_file_reader.py [--models-dir DIR] [--fixture-weights] [--avocodo]
 
@@ -20,7 +19,7 @@ import torch
 
 from InferenceInterfaces.ToucanTTSInterface import ToucanTTSInterface
 
-# the first fourteen lines of the poem the reference's script reads (plain text: only usable when a phonemizer is installed)
+# the first fourteen lines of the poem the reference's script reads (plain text, for the record: what THE_RAVEN_PHONES transcribes)
 THE_RAVEN = [line.strip() for line in """
     Once upon a midnight dreary, while I pondered, weak, and weary,
     Over many a quaint, and curious volume of forgotten lore,
@@ -55,14 +54,6 @@ THE_RAVEN_PHONES = ['~wˈʌns əpˈɑːn ɐ mˈɪdnaɪt dɹˈɪɹi~ wˈaɪl aɪ 
                     '~θɹˈɪld miː~ fˈɪld miː~ wɪð fæntˈæstɪk tˈɛɹɚz~ nˈɛvɚ fˈɛlt bᵻfˈoːɹ.~#']
 
 
-def have_phonemizer():
-    try:
-        import phonemizer  # noqa: F401
-        return True
-    except ImportError:
-        return False
-
-
 def read_texts(model_id, sentence, filename, device="cpu", language="en", speaker_reference=None, faster_vocoder=False, input_is_phones=False):
     """One interface, one language, optionally one reference voice, any number of sentences into one file (reference :8-16)."""
     sentences = [sentence] if isinstance(sentence, str) else list(sentence)
@@ -74,11 +65,10 @@ def read_texts(model_id, sentence, filename, device="cpu", language="en", speake
 
 
 def the_raven(version, model_id="Meta", exec_device="cpu", speed_over_quality=True, speaker_reference=None):
-    """audios/the_raven_<version>.wav (reference :19-41); phoneme strings unless a phonemizer can turn the text into them."""
-    use_phones = not have_phonemizer()
+    """audios/the_raven_<version>.wav (reference :19-41), from the phoneme strings."""
     os.makedirs("audios", exist_ok=True)
-    read_texts(model_id, THE_RAVEN_PHONES if use_phones else THE_RAVEN, os.path.join("audios", f"the_raven_{version}.wav"), device=exec_device,
-               language="en", speaker_reference=speaker_reference, faster_vocoder=speed_over_quality, input_is_phones=use_phones)
+    read_texts(model_id, THE_RAVEN_PHONES, os.path.join("audios", f"the_raven_{version}.wav"), device=exec_device,
+               language="en", speaker_reference=speaker_reference, faster_vocoder=speed_over_quality, input_is_phones=True)
 
 
 if __name__ == '__main__':

@@ -395,7 +395,6 @@ def test_file_reader_harness_end_to_end(tmp_path, monkeypatch):
     spec = importlib.util.spec_from_file_location("reader_harness", os.path.join(root, "run_phoneme_file_reader.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    monkeypatch.setattr(mod, "have_phonemizer", lambda: False)
     mod.the_raven(version="test", model_id="Meta", exec_device="cuda", speed_over_quality=True)
     with wave.open(str(tmp_path / "audios" / "the_raven_test.wav")) as f:
         assert f.getframerate() == 24000 and f.getnchannels() == 1
