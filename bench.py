@@ -43,9 +43,11 @@ def parse_args():
     ap.add_argument("--phones", type=int, default=128)
     ap.add_argument("--frames-per-phone", type=int, default=5)
     ap.add_argument("--vocoder", default="bigvgan", choices=["bigvgan", "hifigan"])
-    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16", "mixed"],
+    ap.add_argument("--dtype", default="bf16", choices=["fp32", "bf16", "fp16", "mixed", "fp32x3", "mixed3"],
                     help="bf16 = BASELINE.json configs[2] (bf16 MFMA GEMMs, fp32 statistics); fp16 = configs[4]'s fp16 MFMA path; "
-                         "fp32 = exact-parity configuration; mixed = acoustic model in fp32 (exact mel parity) + fp16 vocoder")
+                         "fp32 = exact-parity configuration (fp32 matrix instructions); mixed = that acoustic model + fp16 vocoder; "
+                         "fp32x3 = fp32 tensors, dense products as three fp16 MFMAs on split operands (~22 bits per product: keeps the "
+                         "fp32 tolerances against the reference); mixed3 = fp32x3 acoustic model + fp16 vocoder")
     ap.add_argument("--pitch-scale", type=float, default=1.0, help="pitch_variance_scale (configs[4]: 1.3)")
     ap.add_argument("--energy-scale", type=float, default=1.0, help="energy_variance_scale (configs[4]: 0.7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,8 +263,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    precision = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "mixed": "f32"}[args.dtype]
-    voc_precision = "f16" if args.dtype == "mixed" else precision  # mixed: exact-parity acoustic model (fp32) + fp16 vocoder
+    precision = {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "mixed": "f32", "fp32x3": "f32x3", "mixed3": "f32x3"}[args.dtype]
+    voc_precision = "f16" if args.dtype in ("mixed", "mixed3") else precision  # mixed: fp32-tolerance acoustic model + fp16 vocoder
     log(f"building engines (fixture weights, {precision})")
     voc_sd = fw.bigvgan_state_dict() if args.vocoder == "bigvgan" else fw.hifigan_state_dict()
     use_native = args.sequencer == "native" and not args.graphs and not args.fuse_snake
@@ -469,8 +471,8 @@ def main():
         roof = None
         if dominant:
             dom = dom_summary
-            is16 = ("bf16" in dominant or "f16" in dominant or "resblock" in dominant) and "f32" not in dominant
-            peak = PEAK_16BIT_TFLOPS if is16 else PEAK_F32_TFLOPS
+            is16 = ("bf16" in dominant or "f16" in dominant or "resblock" in dominant) and "f32<" not in dominant and "f32x3" not in dominant
+            peak = PEAK_16BIT_TFLOPS if is16 else (PEAK_16BIT_TFLOPS / 3 if "f32x3" in dominant else PEAK_F32_TFLOPS)  # (split fp32: three MFMAs per product)
             traffic, valu_per_elem, src = committed_counters(dominant, dom["bytes_per_launch"])
             mfma_frac = dom["tflops"] / peak
             gbs = dom["bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9
@@ -494,13 +496,15 @@ def main():
                     "flops_per_launch": dom["flops_per_launch"], "share_of_step": dom["total_ms"] / (1e3 * elapsed)}
         fa, fv = algorithmic_flops_per_utterance(L, frames_out // B, args.vocoder)
         step_flops = B * (fa + fv)
-        step_peak = PEAK_F32_TFLOPS if args.dtype == "fp32" else PEAK_16BIT_TFLOPS
+        step_peak = PEAK_F32_TFLOPS if args.dtype == "fp32" else (PEAK_16BIT_TFLOPS / 3 if args.dtype == "fp32x3" else PEAK_16BIT_TFLOPS)
         step_roof = {"flops_per_step": step_flops, "acoustic_flops_per_utterance": fa, "vocoder_flops_per_utterance": fv,
                      "achieved_tflops": step_flops / (elapsed / args.steps) / 1e12, "peak_tflops": step_peak,
                      "frac": step_flops / (elapsed / args.steps) / 1e12 / step_peak,
                      "note": "algorithmic FLOPs of the whole step (SURVEY.md 8(d)) / step time / dense MFMA peak of the vocoder's dtype"}
         cfg_name = {"bf16": "configs[2]", "fp16": "configs[4] (per-GPU shard)", "fp32": "configs[2] shape in fp32",
-                    "mixed": "configs[2] shape, acoustic model in fp32 (exact mel parity) + fp16 vocoder"}[args.dtype]
+                    "mixed": "configs[2] shape, acoustic model in fp32 (exact mel parity) + fp16 vocoder",
+                    "fp32x3": "configs[2] shape, fp32 tensors, dense products as three fp16 MFMAs on split operands",
+                    "mixed3": "configs[2] shape, split-fp32 acoustic model (fp32 tolerances) + fp16 vocoder"}[args.dtype]
         line = {
             "metric": "mel-frames/sec + vocoder RTF @24kHz, batch=32, 1/2/4/8 MI355X",
             "value": world * frames_out * args.steps / elapsed,
@@ -508,13 +512,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "mixed": "f32 (acoustic) + f16 (vocoder)"}[args.dtype], "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16", "mixed": "f32 (acoustic) + f16 (vocoder)", "fp32x3": "f32 as 3 x f16",
+                      "mixed3": "f32 as 3 x f16 (acoustic) + f16 (vocoder)"}[args.dtype], "data": "synthetic",
             "config": {"workload": f"{cfg_name}: batch={B}/GPU x {L} phonemes -> {T} frames, acoustic (PostFlow on) + {args.vocoder}, "
                                    f"gold durations {args.frames_per_phone}/phoneme (duration predictor bypassed; pitch / energy predicted), "
                                    f"pitch scale {args.pitch_scale}, energy scale {args.energy_scale}, fixture weights",
                        "global_batch": world * B, "phones": L, "frames_per_utt": frames_out // B, "vocoder": args.vocoder,
                        "acoustic_dtype": f"{args.dtype} MFMA / f32 activations" if args.dtype in ("bf16", "fp16") else "f32",
-                       "vocoder_dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "fp16", "mixed": "fp16"}[args.dtype], "parallelism": f"dp{world}",
+                       "vocoder_dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "fp16", "mixed": "fp16", "fp32x3": "f32 as 3 x f16", "mixed3": "fp16"}[args.dtype],
+                       "parallelism": f"dp{world}",
                        "hip_graphs": bool(args.graphs),
                        "sequencer": "native stage API (csrc/pipeline.hip)" if use_native else "python (engine.py)",
                        "streams": "2 HIP streams: acoustic model of step k+1 beside the vocoder of step k" if overlap else "1 HIP stream"},

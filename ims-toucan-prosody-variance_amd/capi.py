@@ -13,6 +13,7 @@ MODE_LINEAR, MODE_GLU, MODE_GATED, MODE_COUPLING = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 PRE_NONE, PRE_LRELU, PRE_SNAKE = 0, 1, 2
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_F16 = 0, 1, 2
+COMPUTE_F32X3 = 3  # fp32 tensors, every product as three fp16 MFMAs on split operands (include/toucan_tts.h TTS_COMPUTE_F32X3)
 
 _p = C.c_void_p
 _i = C.c_int32

@@ -59,6 +59,24 @@ __device__ __forceinline__ void store_group(T* dst, float a, float b, float c, f
   }
 }
 
+// fp32 value -> its two fp16 operands of the split product (compute 3): hi = fp16(v), lo' = fp16((v - hi) 2^11).  v - hi is exact
+// in fp32 (hi keeps the leading 11 bits), so hi + 2^-11 lo' carries 22 bits of v; values beyond fp16's range become +-inf (the
+// result is then NaN / inf, never a silently wrong number).
+__device__ __forceinline__ void split3(float v, float& hi, float& lo) {
+  hi = (float)(_Float16)v;
+  lo = (v - hi) * 2048.0f;
+}
+// one 4-channel group into both planes of the split window (lo plane = hi plane + plane_elems)
+__device__ __forceinline__ void store_group_x3(unsigned short* dst, size_t plane_elems, float a, float b, float c, float e) {
+  float h[4], l[4];
+  split3(a, h[0], l[0]);
+  split3(b, h[1], l[1]);
+  split3(c, h[2], l[2]);
+  split3(e, h[3], l[3]);
+  *reinterpret_cast<uint2*>(dst) = make_uint2(pack16<true>(h[0], h[1]), pack16<true>(h[2], h[3]));
+  *reinterpret_cast<uint2*>(dst + plane_elems) = make_uint2(pack16<true>(l[0], l[1]), pack16<true>(l[2], l[3]));
+}
+
 template <bool BF16, bool F16>
 struct Elem {
   using T = unsigned short;
@@ -154,9 +172,15 @@ __device__ __forceinline__ void conv_epilogue16(const TtsConvDesc& d, const TtsT
 // step s, so its global/L2 latency hides under the matrix work; one barrier per step, one more per slab for the
 // activation window.  bf16 uses 64-channel slabs (4 k-steps of v_mfma_f32_32x32x16_bf16 per tap), fp32 32-channel
 // slabs (16 k-steps of v_mfma_f32_32x32x2_f32); either way a weight slab is BN*16/32 KiB.
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16>
+// X3 (compute 3): fp32 activations and weights, every product as THREE fp16 matrix instructions on split operands -
+//   a b ~= hi_a hi_b + 2^-11 (hi_a lo'_b + lo'_a hi_b),   hi = fp16(v), lo' = fp16((v - hi) 2^11),   fp32 accumulation
+// (two accumulator sets: the hi.hi sums and the cross sums, combined once before the epilogue) - ~22 significant bits per product
+// at 16/3 of the fp32 matrix rate.  The window and the weight slabs carry two fp16 planes each (weights pre-split by the host:
+// w16 = [hi | lo'] planes of [tap][cin_pad/8][wn][8]); everything else - tiling, staging, epilogue - is the 16-bit path's.
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16, bool X3 = false>
 __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   static_assert(BF16 || !F16, "F16 selects the element format of the 16-bit MFMA path");
+  static_assert(!X3 || (BF16 && F16 && !SNAKE), "the split fp32 product runs on the fp16 path");
   using C = ConvCfg<TM, TN, WAVES_M, WAVES_N, DUAL>;
   using ET = typename Elem<BF16, F16>::T;
   constexpr int BM = C::BM, BN = C::BN;
@@ -178,13 +202,14 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   // The 64-row small-batch form keeps TWO activation windows (a window is only 8-20 KB there): the window of channel slab
   // ch+1 is requested into registers while slab ch multiplies and written to the other buffer afterwards, so a slab boundary
   // no longer exposes a global-load round trip (at batch 1 that round trip, not the MFMAs, set the step time: ~2.5 us/slab).
-  constexpr bool WIN2 = BM == 64 && !SNAKE;
+  constexpr bool WIN2 = BM == 64 && !SNAKE && !X3;
+  constexpr int NP = X3 ? 2 : 1;                     // operand planes (hi, lo')
   constexpr int GPR = BK / 4;                        // 4-channel groups per window row
   constexpr int PF = BF16 ? 5 : 3;                   // 16-byte register groups per thread: (64 + 16) rows x GPR / 256, rounded up
   const size_t xs_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7;
-  ET* xs0 = reinterpret_cast<ET*>(lds_raw);                                 // [1 or 2][win_rows][XP]
-  ET* ws = xs0 + (WIN2 ? 2 : 1) * xs_elems;                                 // [2][NH][BK*BN]
-  constexpr int WBUF = NH * BK * BN;
+  ET* xs0 = reinterpret_cast<ET*>(lds_raw);                                 // [1 or 2][win_rows][XP]  (X3: [2 planes][win_rows][XP])
+  ET* ws = xs0 + ((WIN2 || X3) ? 2 : 1) * xs_elems;                         // [2][NH][NP][BK*BN]
+  constexpr int WBUF = NH * NP * BK * BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -195,6 +220,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   const int lk = lane >> 5;
 
   f32x16 acc[NH][TM][TN];
+  f32x16 accx[X3 ? NH : 1][X3 ? TM : 1][X3 ? TN : 1];  // X3: the cross sums hi.lo' + lo'.hi (scaled by 2^-11 at the end)
 #pragma unroll
   for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -202,7 +228,10 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          acc[h][i][j][r] = 0.0f;
+          if constexpr (X3) accx[h][i][j][r] = 0.0f;
+        }
 
   const int row_first = tile.row0 - d.pad_left;  // packed row of window row 0
   const bool x_bf16 = d.io_flags & TTS_IO_X_BF16;  // x is a 16-bit tensor ...
@@ -214,7 +243,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   const int n_chunks = (d.cin_pad + BK - 1) / BK;
   const int total_steps = n_chunks * d.taps;
 
-  uint4 wreg[NH][UPT];
+  uint4 wreg[NH][NP][UPT];
+  const size_t w_plane = (size_t)d.taps * d.cin_pad * d.wn;  // X3: elements between the hi and the lo' plane of the packed weights
   // 16-byte unit u of the slab of (chunk c0, tap): where it lives in global memory and in the LDS slab
   auto load_slab = [&](int c0, int tap, int kchunk) __attribute__((always_inline)) {
 #pragma unroll
@@ -237,8 +267,11 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           k = ok ? k : 0;
           goff = ((size_t)tap * d.cin_pad + c0 + k) * d.wn + n0 + h * d.half_pad + c4;
         }
-        const uint4 v = *reinterpret_cast<const uint4*>(W + goff);
-        wreg[h][q] = ok ? v : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) {
+          const uint4 v = *reinterpret_cast<const uint4*>(W + goff + pl * w_plane);
+          wreg[h][pl][q] = ok ? v : make_uint4(0, 0, 0, 0);
+        }
       }
   };
   auto store_slab = [&](int buf) __attribute__((always_inline)) {
@@ -247,7 +280,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 #pragma unroll
       for (int q = 0; q < UPT; ++q) {
         const int u = tid + q * 256;
-        *reinterpret_cast<uint4*>(ws + (size_t)buf * WBUF + h * BK * BN + u * EPU) = wreg[h][q];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+          *reinterpret_cast<uint4*>(ws + (size_t)buf * WBUF + (h * NP + pl) * BK * BN + u * EPU) = wreg[h][pl][q];
       }
   };
 
@@ -448,6 +483,10 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
                             __builtin_bit_cast(float, raw[p].w));
           if (!okv[p]) v = make_float4(0.f, 0.f, 0.f, 0.f);
           ET* dst = xs + wr * XP + c4;
+          if constexpr (X3)
+            store_group_x3(dst, xs_elems, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
+                           pre_activation(v.z, d.pre_act, d.pre_slope), pre_activation(v.w, d.pre_act, d.pre_slope));
+          else
           store_group<BF16, F16>(dst, pre_activation(v.x, d.pre_act, d.pre_slope), pre_activation(v.y, d.pre_act, d.pre_slope),
                             pre_activation(v.z, d.pre_act, d.pre_slope), pre_activation(v.w, d.pre_act, d.pre_slope));
         }
@@ -459,7 +498,14 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         float v = 0.f;
         if (gr >= tile.seq_begin && gr < tile.seq_end && (c0 + c) < d.cin)
           v = x_bf16 ? load16(xh[(size_t)gr * d.ldx + c0 + c], x_f16) : d.x[(size_t)gr * d.ldx + c0 + c];
+        if constexpr (X3) {
+          float hi, lo;
+          split3(pre_activation(v, d.pre_act, d.pre_slope), hi, lo);
+          xs[wr * XP + c] = f32_to_f16(hi);
+          xs[xs_elems + wr * XP + c] = f32_to_f16(lo);
+        } else {
         xs[wr * XP + c] = Elem<BF16, F16>::cvt(pre_activation(v, d.pre_act, d.pre_slope));
+        }
       }
     }
     for (int tap = 0; tap < d.taps; ++tap, ++step) {
@@ -475,21 +521,30 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
       if constexpr (BF16) {
         const int ksteps = kchunk >> 4;
         for (int ks = 0; ks < ksteps; ++ks) {
-          bf16x8 a[TM];
+          bf16x8 a[TM], al[X3 ? TM : 1];
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i) {
             a[i] = *reinterpret_cast<const bf16x8*>(xs + (wm * TM * 32 + i * 32 + lrow + tap * d.dil) * XP + ks * 16 + lk * 8);
+            if constexpr (X3) al[i] = *reinterpret_cast<const bf16x8*>(xs + xs_elems + (wm * TM * 32 + i * 32 + lrow + tap * d.dil) * XP + ks * 16 + lk * 8);
+          }
 #pragma unroll
           for (int h = 0; h < NH; ++h) {
-            bf16x8 b[TN];
+            bf16x8 b[TN], bl[X3 ? TN : 1];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              b[j] = *reinterpret_cast<const bf16x8*>(wb + h * BK * BN + ((ks * 2 + lk) * BN + wn * TN * 32 + j * 32 + lrow) * 8);
+            for (int j = 0; j < TN; ++j) {
+              b[j] = *reinterpret_cast<const bf16x8*>(wb + h * NP * BK * BN + ((ks * 2 + lk) * BN + wn * TN * 32 + j * 32 + lrow) * 8);
+              if constexpr (X3) bl[j] = *reinterpret_cast<const bf16x8*>(wb + (h * NP + 1) * BK * BN + ((ks * 2 + lk) * BN + wn * TN * 32 + j * 32 + lrow) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-              for (int j = 0; j < TN; ++j)
+              for (int j = 0; j < TN; ++j) {
                 acc[h][i][j] = mfma16<F16>(a[i], b[j], acc[h][i][j]);
+                if constexpr (X3) {
+                  accx[h][i][j] = mfma16<true>(a[i], bl[j], accx[h][i][j]);
+                  accx[h][i][j] = mfma16<true>(al[i], b[j], accx[h][i][j]);
+                }
+              }
           }
         }
       } else {
@@ -521,6 +576,16 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
     if (win2 && ch + 1 < n_chunks) win_commit(c0 + BK, xs0 + ((ch & 1) ? 0 : xs_elems));
   }
 
+  if constexpr (X3) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[h][i][j][r] = fmaf(accx[h][i][j][r], 1.0f / 2048.0f, acc[h][i][j][r]);
+  }
   conv_epilogue<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
 }
 
@@ -890,7 +955,7 @@ static bool small_form_ok(int cout, int mode, int cols) {
   return mode != TTS_MODE_LINEAR || cout > 64;
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16 = false>
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16 = false, bool X3 = false>
 static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   using C = ConvCfg<TM, TN, WAVES_M, WAVES_N, DUAL>;
   constexpr int BK = BF16 ? 64 : 32, ESZ = BF16 ? 2 : 4, NH = DUAL ? 2 : 1;
@@ -900,9 +965,9 @@ static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   const int n_tiles_n = ((DUAL ? d.half_pad : d.wn) + C::BN - 1) / C::BN;
   dim3 grid(d.n_tiles, n_tiles_n), block(256);
   const size_t xs_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7;
-  const size_t lds = ((C::BM == 64 && !SNAKE ? 2 : 1) * xs_elems + (size_t)2 * NH * BK * C::BN) * ESZ;
+  const size_t lds = (((C::BM == 64 && !SNAKE) || X3 ? 2 : 1) * xs_elems + (size_t)2 * NH * (X3 ? 2 : 1) * BK * C::BN) * ESZ;
   TTS_CHECK_ARG(lds <= 160 * 1024, "conv1d: LDS %zu B exceeds 160 KiB (taps %d dil %d)", lds, d.taps, d.dil);
-  auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE, F16>;
+  auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE, F16, X3>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised
   if (lds > 64 * 1024) {
     const hipError_t e = raise_lds_limit(reinterpret_cast<const void*>(k), lds_raised);
@@ -918,6 +983,7 @@ static int launch_one(const TtsConvDesc& d, hipStream_t st) {
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL>
 static int launch_cfg(const TtsConvDesc& d, hipStream_t st) {
   if constexpr (!DUAL) {
+    TTS_CHECK_ARG(!(d.pre_act == TTS_PRE_SNAKE && d.compute == 3), "conv1d: the snake prologue is not available with the split fp32 product");
     if (d.pre_act == TTS_PRE_SNAKE) {  // only the (non-dual) vocoder convs carry the snake prologue
       if (d.compute == 0) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, false, true>(d, st);
       if (d.compute == 2) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, true, true>(d, st);
@@ -925,6 +991,7 @@ static int launch_cfg(const TtsConvDesc& d, hipStream_t st) {
     }
   }
   TTS_CHECK_ARG(d.pre_act != TTS_PRE_SNAKE, "conv1d: the snake prologue is not available in the dual modes");
+  if (d.compute == 3) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, false, true, true>(d, st);
   if (d.compute == 0) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, false, false>(d, st);
   if (d.compute == 2) return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, false, true>(d, st);
   return launch_one<TM, TN, WAVES_M, WAVES_N, DUAL, true, false>(d, st);
@@ -932,6 +999,7 @@ static int launch_cfg(const TtsConvDesc& d, hipStream_t st) {
 
 // the LDS-free 1-tap path: single tap, no padding, whole 64-channel (bf16) / 32-channel (fp32) slabs, 16-byte aligned rows
 static bool gemm_rows_ok(const TtsConvDesc& d) {
+  if (d.compute == 3) return false;  // (the split fp32 product has the LDS-staged forms only)
   if (d.taps != 1 || d.pad_left != 0 || d.pre_act == TTS_PRE_SNAKE || d.cin != d.cin_pad) return false;
   const bool xb = d.io_flags & TTS_IO_X_BF16;
   if (xb && d.compute == 0) return false;
@@ -1004,9 +1072,10 @@ int conv1d_dispatch(const TtsConvDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.cin > 0 && d.cout > 0 && d.taps > 0 && d.dil > 0, "conv1d: bad dims");
   TTS_CHECK_ARG(d.cin_pad % 32 == 0 && d.cin_pad >= d.cin, "conv1d: cin_pad %d must be a multiple of 32 >= cin %d", d.cin_pad, d.cin);
   TTS_CHECK_ARG(d.mode >= 0 && d.mode <= 3, "conv1d: bad mode %d", d.mode);
-  TTS_CHECK_ARG(d.compute >= 0 && d.compute <= 2, "conv1d: bad compute %d (0 fp32, 1 bf16, 2 fp16)", d.compute);
-  TTS_CHECK_ARG(d.compute == 0 || ((d.io_flags & TTS_IO_F16) != 0) == (d.compute == 2) || !(d.io_flags & 7),
+  TTS_CHECK_ARG(d.compute >= 0 && d.compute <= 3, "conv1d: bad compute %d (0 fp32, 1 bf16, 2 fp16, 3 split fp32)", d.compute);
+  TTS_CHECK_ARG(d.compute == 0 || d.compute == 3 || ((d.io_flags & TTS_IO_F16) != 0) == (d.compute == 2) || !(d.io_flags & 7),
                 "conv1d: the 16-bit tensors of a bf16 / fp16 call must be in the call's own format");
+  TTS_CHECK_ARG(d.compute != 3 || !(d.io_flags & 7), "conv1d: the split fp32 product takes and returns fp32 tensors");
   TTS_CHECK_ARG(d.mode != TTS_MODE_COUPLING || d.aux, "conv1d: coupling mode needs aux");
   TTS_CHECK_ARG(d.pre_act != TTS_PRE_SNAKE || (d.snake_alpha && d.snake_beta && d.snake_filt), "conv1d: PRE_SNAKE needs alpha/beta/filter");
   if (d.n_tiles == 0) return TTS_OK;

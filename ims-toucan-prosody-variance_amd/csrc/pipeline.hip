@@ -145,6 +145,8 @@ namespace {
     if (rc_ != TTS_OK) return rc_; \
   } while (0)
 
+bool is16(const Handle* h);
+
 int hip_ok(hipError_t e, const char* what) {
   if (e == hipSuccess) return TTS_OK;
   set_error("%s: %s", what, hipGetErrorString(e));
@@ -347,7 +349,14 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
   TTS_TRY(tiles_of(h, l, tile_rows, st, &tt));
   TtsConvDesc d;
   memset(&d, 0, sizeof(d));
-  const bool use16 = !o.fp32_only && h->cfg.precision != TTS_COMPUTE_F32 && cw.w16 != nullptr;
+  bool use16 = !o.fp32_only && h->cfg.precision != TTS_COMPUTE_F32 && cw.w16 != nullptr;
+  if (use16 && cw.compute16 == TTS_COMPUTE_F32X3) {
+    // the split fp32 product (same rule as engine.Ops.conv): not in the phoneme stages (exact fp32 upstream of the rounded
+    // durations), and not where the exact fp32 split-K form is the fast one (frame stages on grids of a few workgroups)
+    const int cols = cw.mode == TTS_MODE_LINEAR ? cw.wn : cw.half_pad;
+    const bool small = (long long)tt.n * (tile_rows / 64) * ((cols + 63) / 64) <= 128;
+    if (h->split_mode == 2 || (h->split_mode == 1 && small)) use16 = false;
+  }
   d.x = static_cast<const float*>(x.p); d.ldx = x.ld; d.cin = cw.cin;
   d.w = use16 ? cw.w16 : cw.w; d.cin_pad = cw.cin_pad; d.wn = cw.wn; d.half_pad = cw.half_pad;
   d.bias = cw.bias;
@@ -367,14 +376,14 @@ int conv(Handle* h, const ConvW& cw, T2 x, T2 y, const Layout& l, hipStream_t st
                ((any16 && h->cfg.precision == TTS_COMPUTE_F16) ? TTS_IO_F16 : 0);
   // the fp32 configuration only: the fp32 layers of a 16-bit configuration keep one accumulation order at every batch size (an
   // utterance's result there does not depend on the batch it is in, bit for bit - tests/test_gpu_e2e.py asserts it)
-  if (h->split_mode && !o.no_split_k && h->cfg.precision == TTS_COMPUTE_F32 && d.compute == TTS_COMPUTE_F32)
+  if (h->split_mode && !o.no_split_k && !is16(h) && d.compute == TTS_COMPUTE_F32)
     d.io_flags |= h->split_mode == 2 ? TTS_IO_SPLIT_K_ALWAYS : TTS_IO_SPLIT_K;
   d.tiles = tt.dev; d.n_tiles = tt.n; d.tile_rows = tile_rows;
   if (h->prof_on) {  // same class names and algorithmic work as profiling.py (kernel_class / ConvTimer.add)
     const bool dual = cw.mode != TTS_MODE_LINEAR;
     const int bm = tile_rows != cw.tile_rows ? tile_rows : cw.tile_rows, bn = tile_rows != cw.tile_rows ? 64 : cw.n_tile;
     char name[96];
-    int nlen = snprintf(name, sizeof(name), "conv1d_%s<%dx%d%s>", d.compute == TTS_COMPUTE_F32 ? "f32" : (d.compute == TTS_COMPUTE_BF16 ? "bf16" : "f16"),
+    int nlen = snprintf(name, sizeof(name), "conv1d_%s<%dx%d%s>", d.compute == TTS_COMPUTE_F32 ? "f32" : (d.compute == TTS_COMPUTE_BF16 ? "bf16" : (d.compute == TTS_COMPUTE_F16 ? "f16" : "f32x3")),
                         bm, bn, dual ? ",dual" : "");
     if (h->prof_detail)  // per-shape classes (tools/conv_shapes.py): where the small-GEMM time goes
       snprintf(name + nlen, sizeof(name) - nlen, "[%dx%d k%d r%d]", cw.cin, cw.cout * (dual ? 2 : 1), cw.taps, l.total);
@@ -425,7 +434,10 @@ int block_of(const Handle* h, const std::string& p, Block* b) {
   return TTS_OK;
 }
 
-int bits16(const Handle* h) { return h->cfg.precision == TTS_COMPUTE_F32 ? 32 : 16; }
+// 16-bit configuration (bf16 / fp16: 16-bit tensors between the fused kernels)?  TTS_COMPUTE_F32X3 is a 32-bit configuration in
+// every respect but the dense products of its frame stages and vocoder (three fp16 MFMAs on split operands)
+bool is16(const Handle* h) { return h->cfg.precision == TTS_COMPUTE_BF16 || h->cfg.precision == TTS_COMPUTE_F16; }
+int bits16(const Handle* h) { return is16(h) ? 16 : 32; }
 
 // relative position tables of both stacks for positions -(pmax-1) .. pmax-1 (Attention.py:177, PositionalEncoding.py:90-130):
 // ptab[s][l][pmax - 1 + p] = linear_pos_l(pe(p)); the sinusoid table "pe" is uploaded by the host (fp32, built like the reference)
@@ -607,7 +619,7 @@ int predictor(Handle* h, const char* name, int layers, int first_cln, float* out
 // ======================================================================================================================
 int pipeline_create(const TtsConfig* cfg, Handle** out) {
   TTS_CHECK_ARG(cfg && out, "tts_create: null pointer");
-  TTS_CHECK_ARG(cfg->precision >= 0 && cfg->precision <= 2, "tts_create: precision %d (0 fp32, 1 bf16, 2 fp16)", cfg->precision);
+  TTS_CHECK_ARG(cfg->precision >= 0 && cfg->precision <= 3, "tts_create: precision %d (0 fp32, 1 bf16, 2 fp16, 3 split fp32)", cfg->precision);
   TTS_CHECK_ARG(cfg->vocoder >= 0 && cfg->vocoder <= 2, "tts_create: vocoder %d (0 none, 1 hifigan, 2 bigvgan)", cfg->vocoder);
   Handle* h = new Handle();
   h->cfg = *cfg;
@@ -674,7 +686,7 @@ long long pipeline_workspace_bytes(const Handle* h, int B, int Lmax, int Tmax) {
   const size_t RP = (size_t)B * Lmax, RF = (size_t)B * (Tmax + 1);  // (frame layouts start every utterance on an even row)
   size_t total = with_growth_slack(phone_arena_bytes(RP, B)) + with_growth_slack(frame_arena_bytes(RF));
   if (h->cfg.vocoder) {
-    const bool fused_mode = h->cfg.precision != TTS_COMPUTE_F32, big = h->cfg.vocoder == 2;
+    const bool fused_mode = is16(h), big = h->cfg.vocoder == 2;
     for (int a = 0; a < 2; ++a) total += with_growth_slack(vocoder_arena_bytes(RF, a, fused_mode, big));
   }
   return (long long)total;
@@ -893,7 +905,7 @@ int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
   TTS_TRY(hip_ok(hipMemcpyAsync(x, z_noise, (size_t)RS * 160 * 4, hipMemcpyDeviceToDevice, st), "flow noise"));
   TTS_ALLOC(hs, a, float, (size_t)RS * 2 * ATT);  // [hidden state | skip sum]
   // 16-bit configurations: one launch per WaveNet layer (tts_wavenet_layer); the state ping-pongs between hs and hs2
-  const bool fused = h->cfg.precision != TTS_COMPUTE_F32 && !h->no_fused_wavenet;
+  const bool fused = is16(h) && !h->no_fused_wavenet;
   float* hs2 = nullptr;
   TileTab t64;
   if (fused) {

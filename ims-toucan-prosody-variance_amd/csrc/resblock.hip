@@ -101,7 +101,10 @@ __device__ unsigned long long g_rb_trace[RB_TRACE_MAX][16];
 // C == 256: conv1 on M1 = 128 rows (4 waves, 8 accumulators each), 96 output rows, 64-channel slabs (LDS: t1 alone is 66 KB).
 template <int C>
 struct RbCfg {
-  static constexpr int M1 = C == 256 ? 128 : 256;
+  // C = 64: 16 wavefronts on a 512-row window (480 output rows): ONE workgroup per CU does what two did - the same occupancy in
+  // the vector phases - but shares every weight slab, reads half the halo, and a conv step carries two taps (32 matrix
+  // instructions per SIMD and barrier instead of 16)
+  static constexpr int M1 = C == 256 ? 128 : (C == 64 ? 512 : 256);
   static constexpr int BM = M1 - 2 * RB_LEAD;
   static constexpr int THREADS = 2 * M1;
   static constexpr int KC = C == 256 ? 64 : C;
@@ -124,7 +127,8 @@ struct RbCfg {
   // weight slabs through a three-slot LDS-DMA ring (see the kernel): slabs per tap
   static constexpr bool DMA = C == 64 || C == 128;
   static constexpr int SPLIT = C == 128 ? 2 : 1;
-  static constexpr int ring_elems(int taps) { return DMA ? 3 * (KC / SPLIT) * C : 2 * (taps < TPS ? taps : TPS) * KC * C; }
+  static constexpr int DTAPS = C == 64 ? 2 : 1;       // taps per DMA slab (SPLIT == 1 only)
+  static constexpr int ring_elems(int taps) { return DMA ? 3 * DTAPS * (KC / SPLIT) * C : 2 * (taps < TPS ? taps : TPS) * KC * C; }
 };
 
 // register-staged weight slab (up to 4 x 16 bytes per thread, named members so that it never becomes a stack array):
@@ -228,7 +232,9 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   constexpr bool DMA = RbCfg<C>::DMA;
   constexpr int SPLIT = RbCfg<C>::SPLIT;            // slabs per tap
   constexpr int SLAB_K = KC / SPLIT;                // input channels per DMA slab
-  constexpr int DMA_ELEMS = SLAB_K * C;             // 16-bit elements per ring slot
+  constexpr int DTAPS = RbCfg<C>::DTAPS;            // taps per DMA slab
+  static_assert(DTAPS == 1 || SPLIT == 1, "multi-tap slabs carry whole taps");
+  constexpr int DMA_ELEMS = DTAPS * SLAB_K * C;     // 16-bit elements per ring slot
   constexpr int DMA_PW = DMA ? DMA_ELEMS / 8 / RB_THREADS : 1;  // global_load_lds instructions per wavefront and slab
   static_assert(!DMA || (DMA_ELEMS / 8) % RB_THREADS == 0, "a DMA slab is whole rounds of the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -299,7 +305,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (prologue only: the tile loop re-derives them, see there)
   const bool snake = d.act == TTS_PRE_SNAKE;
   const unsigned short* __restrict__ xh = reinterpret_cast<const unsigned short*>(d.x);  // x viewed as bf16 (io_bf16)
-  const int spc = DMA ? d.taps * SPLIT : (d.taps + TPS - 1) / TPS;  // slab steps per channel chunk
+  const int spc = DMA ? (d.taps + DTAPS - 1) / DTAPS * SPLIT : (d.taps + TPS - 1) / TPS;  // slab steps per channel chunk
   const int steps1 = NCH * spc, total_steps = 2 * steps1;
   const int slab_alloc = DMA ? DMA_ELEMS : (d.taps < TPS ? d.taps : TPS) * TAPW;  // LDS elements per slab buffer
 
@@ -355,15 +361,19 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     if constexpr (DMA) {
       const bool second = step >= steps1;
       const int sidx = second ? step - steps1 : step;
-      const int tap = sidx / SPLIT, half = sidx % SPLIT;
+      const int tap = sidx / SPLIT * DTAPS, half = sidx % SPLIT;
       const unsigned short* W = reinterpret_cast<const unsigned short*>(second ? d.w2 : d.w1);
       const unsigned short* src = W + ((size_t)tap * (C / 8) + half * (SLAB_K / 8)) * C * 8;
       unsigned short* dst = ws + (size_t)slot * DMA_ELEMS;
       const int wv = __builtin_amdgcn_readfirstlane(tid_ >> 6), ln = tid_ & 63;
+      // (a conv's last slab may carry fewer taps: the units behind them re-read the slab's last valid unit - never past the weights)
+      const int valid = (d.taps - tap < DTAPS ? d.taps - tap : DTAPS) * (SLAB_K / 8) * C;
 #pragma unroll
       for (int q = 0; q < DMA_PW; ++q) {
         const int u0 = q * RB_THREADS + wv * 64;
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(u0 + ln) * 8),
+        int u = u0 + ln;
+        if constexpr (DTAPS > 1) u = u < valid ? u : valid - 1;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)u * 8),
                                          (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 8), 16, 0, 0);
       }
     }
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
           }
           stage_commit(tile, base);
         }
-        constexpr int CB = C / 16, SEG = 8 / CB;
+        constexpr int CB = C / 16, SEG = (RB_THREADS / 64) / CB;
         const int cb = wave % CB, seg = wave / CB;
         const int tiles_total = (win_rows + 15) / 16;
         const int t_lo = seg * tiles_total / SEG, t_hi = (seg + 1) * tiles_total / SEG;
@@ -679,15 +689,21 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     }
     RB_SETPRIO(RB_PRIO_CONV);
     if constexpr (DMA) {
-      for (int tap = 0; tap < d.taps; ++tap) {
+      for (int tap0 = 0; tap0 < d.taps; tap0 += DTAPS) {
 #pragma unroll
         for (int half = 0; half < SPLIT; ++half, ++step) {
           dma_step_barrier(std::integral_constant<int, DMA_PW>{});
           int nxt = step + 2;  // (wraps into the next tile's first slabs; issued even without a next tile - drained before the kernel ends)
           nxt = nxt >= total_steps ? nxt - total_steps : nxt;
           const unsigned short* wb = ws + (size_t)ring_pos * DMA_ELEMS;
-          rb_conv_tap<C, SLAB_K / 16, TN, F16>(xa + (wave * 32 + lrow + tap * d.dil) * XP + half * SLAB_K + lk * 8, wb + (lk * C + lrow) * 8, acc,
+          const unsigned short* ap = xa + (wave * 32 + lrow + tap0 * d.dil) * XP + half * SLAB_K + lk * 8;
+          rb_conv_tap<C, SLAB_K / 16, TN, F16>(ap, wb + (lk * C + lrow) * 8, acc,
                                                [&]() __attribute__((always_inline)) { dma_issue(nxt, ring_pos >= 1 ? ring_pos - 1 : 2, tid); });
+          if constexpr (DTAPS > 1) {
+#pragma unroll
+            for (int tt = 1; tt < DTAPS; ++tt)
+              if (tap0 + tt < d.taps) rb_conv_tap<C, SLAB_K / 16, TN, F16>(ap + tt * d.dil * XP, wb + (size_t)tt * SLAB_K * C + (lk * C + lrow) * 8, acc);
+          }
           ring_pos = ring_pos == 2 ? 0 : ring_pos + 1;
         }
       }
@@ -766,7 +782,7 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   if (MFIR && snake) {
     if constexpr (MFIR) {
       // act2 in place on t1 (rows [0, M1) of the window; the 6 rows on either side only feed outputs conv2 never reads)
-      constexpr int CB = C / 16, SEG = 8 / CB;
+      constexpr int CB = C / 16, SEG = (RB_THREADS / 64) / CB;
       const int cb = wave % CB, seg = wave / CB;
       constexpr int tiles_total = RB_M1 / 16;
       SnakeFir fir;
@@ -894,7 +910,13 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     };
     if (wave < RB_BM / 32) {
       const unsigned short* wb = ws + (size_t)ring_pos * DMA_ELEMS;
-      rb_conv_tap<C, SLAB_K / 16, TN, F16>(t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + half * SLAB_K + lk * 8, wb + (lk * C + lrow) * 8, acc, issue);
+      const unsigned short* ap = t1 + (RB_LEAD - h2 + wave * 32 + lrow + tap) * TP + half * SLAB_K + lk * 8;
+      rb_conv_tap<C, SLAB_K / 16, TN, F16>(ap, wb + (lk * C + lrow) * 8, acc, issue);
+      if constexpr (DTAPS > 1) {
+#pragma unroll
+        for (int tt = 1; tt < DTAPS; ++tt)
+          if (tap + tt < d.taps) rb_conv_tap<C, SLAB_K / 16, TN, F16>(ap + tt * TP, wb + (size_t)tt * SLAB_K * C + (lk * C + lrow) * 8, acc);
+      }
     } else {
       issue();
     }
@@ -906,8 +928,8 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     constexpr int KEEP1 = DMA_PW + (PREFETCH_RES ? TN * 4 : 0);  // the step behind the peeled one: the residual loads may stay in flight
     conv2_step_dma(std::true_type{}, std::integral_constant<int, DMA_PW>{}, 0, 0);
     if constexpr (SPLIT == 2) conv2_step_dma(std::false_type{}, std::integral_constant<int, KEEP1>{}, 0, 1);
-    for (int tap = 1; tap < d.taps; ++tap) {
-      if (SPLIT == 1 && tap == 1) conv2_step_dma(std::false_type{}, std::integral_constant<int, KEEP1>{}, tap, 0);
+    for (int tap = DTAPS; tap < d.taps; tap += DTAPS) {
+      if (SPLIT == 1 && tap == DTAPS) conv2_step_dma(std::false_type{}, std::integral_constant<int, KEEP1>{}, tap, 0);
       else conv2_step_dma(std::false_type{}, std::integral_constant<int, DMA_PW>{}, tap, 0);
       if constexpr (SPLIT == 2) conv2_step_dma(std::false_type{}, std::integral_constant<int, DMA_PW>{}, tap, 1);
     }
@@ -1176,7 +1198,7 @@ int snake_fir_table(const float* f, void* table) {
   return TTS_OK;
 }
 
-int resblock_tile_rows(int c) { return c == 256 ? RbCfg<256>::BM : RbCfg<32>::BM; }
+int resblock_tile_rows(int c) { return c == 256 ? RbCfg<256>::BM : (c == 64 ? RbCfg<64>::BM : RbCfg<32>::BM); }
 
 int resblock_step(const TtsResblockDesc& d, hipStream_t st) {
   TTS_CHECK_ARG(d.x && d.y && d.w1 && d.w2 && d.b1 && d.b2 && d.tiles, "resblock_step: null pointer");

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import capi, packing
-from .capi import (ACT_NONE, ACT_RELU, ACT_TANH, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, MODE_COUPLING, MODE_GATED, MODE_GLU,
+from .capi import (ACT_NONE, ACT_RELU, ACT_TANH, COMPUTE_BF16, COMPUTE_F16, COMPUTE_F32, COMPUTE_F32X3, MODE_COUPLING, MODE_GATED, MODE_GLU,
                    MODE_LINEAR, PRE_LRELU, PRE_NONE, PRE_SNAKE)
 from .ragged import Ragged
 
@@ -36,10 +36,15 @@ def _f16_flag(*ts):
 
 
 def precision_of(bf16, precision):
-    """(`bf16` flag of the older API, `precision` in {None, "f32", "bf16", "f16"}) -> (name, pack argument, compute, torch dtype)."""
+    """(`bf16` flag of the older API, `precision` in {None, "f32", "f32x3", "bf16", "f16"}) -> (name, pack argument, compute, torch
+    dtype of the 16-bit tensors).  "f32x3": fp32 tensors everywhere, the dense products of the frame stages as three fp16 MFMAs on
+    split operands (TTS_COMPUTE_F32X3: ~22 bits per product at 16/3 of the fp32 matrix rate) - a 32-bit configuration in every
+    other respect (no fused 16-bit kernels, fp32 attention, exact fp32 phoneme stages)."""
     name = precision if precision is not None else ("bf16" if bf16 else "f32")
     if name in ("fp32", "f32"):
         return "f32", False, COMPUTE_F32, torch.float32
+    if name in ("f32x3", "fp32x3"):
+        return "f32x3", "x3", COMPUTE_F32X3, torch.float32
     if name == "bf16":
         return "bf16", "bf16", COMPUTE_BF16, torch.bfloat16
     if name in ("fp16", "f16"):
@@ -100,6 +105,13 @@ class Ops:
         d = capi.TtsConvDesc()
         d.x, d.ldx, d.cin = x.data_ptr(), _ld(x), cw.cin
         use_bf16 = compute != COMPUTE_F32 and cw.w16 is not None  # the conv then runs in the format of its own 16-bit copy
+        if use_bf16 and cw.compute16 == COMPUTE_F32X3:
+            # the split fp32 product (same rule as pipeline.hip conv()): not in the phoneme stages (exact fp32 upstream of the rounded
+            # durations), and not where the exact fp32 split-K form is the fast one (frame stages on grids of a few workgroups)
+            cols = cw.wn if cw.mode == MODE_LINEAR else cw.half_pad
+            small = n_tiles * (tile_rows // 64) * (-(-cols // 64)) <= 128
+            if self.split_k == 2 or (self.split_k == 1 and small):
+                use_bf16 = False
         d.w = cw.w16.data_ptr() if use_bf16 else cw.w.data_ptr()
         d.cin_pad, d.wn, d.half_pad = cw.cin_pad, cw.wn, cw.half_pad
         d.bias = _ptr(cw.bias)
@@ -118,7 +130,7 @@ class Ops:
         # 16-bit tensors in HBM are recognised by dtype (strides are already in elements)
         d.io_flags = (capi.IO_X_BF16 if _is_bf16(x) else 0) | (capi.IO_Y_BF16 if _is_bf16(y) else 0) | (capi.IO_RES_BF16 if _is_bf16(res) else 0) \
             | _f16_flag(x, y, res)
-        if split_k and self.split_k and self.default_compute == COMPUTE_F32 and d.compute == COMPUTE_F32:
+        if split_k and self.split_k and self.default_compute in (COMPUTE_F32, COMPUTE_F32X3) and d.compute == COMPUTE_F32:
             # same rule as pipeline.hip conv(): the fp32 configuration only - the fp32 layers of a 16-bit configuration keep one
             # accumulation order at every batch size (an utterance's result there does not depend on the batch it is in, bit for bit)
             d.io_flags |= capi.IO_SPLIT_K_ALWAYS if self.split_k == 2 else capi.IO_SPLIT_K
@@ -239,7 +251,7 @@ class Ops:
             capi.check(self.lib.tts_relpos_attention_f16(*args, self.stream()), "tts_relpos_attention_f16")
             return ctx
         if flags is None:
-            flags = 0 if self.default_compute != COMPUTE_F32 else {0: 0, 1: capi.ATT_KEY_SPLIT, 2: capi.ATT_KEY_SPLIT_ALWAYS}[self.split_k]
+            flags = 0 if self.default_compute not in (COMPUTE_F32, COMPUTE_F32X3) else {0: 0, 1: capi.ATT_KEY_SPLIT, 2: capi.ATT_KEY_SPLIT_ALWAYS}[self.split_k]
         capi.check(self.lib.tts_relpos_attention(*args, flags, self.stream()), "tts_relpos_attention")
         return ctx
 
@@ -360,7 +372,7 @@ class ConformerWeights:
                 blk[ff + ".w2"] = pack(sd[p + ff + ".w_2.weight"], sd[p + ff + ".w_2.bias"], device)
                 # 16-bit configurations, kernel size 1: the whole module is one launch (tts_ffn_fused) on weights in its fragment order
                 w1 = np.asarray(sd[p + ff + ".w_1.weight"])
-                if bf16 and not os.environ.get("TOUCAN_NO_FUSED_FFN") and (w1.ndim == 2 or w1.shape[2] == 1) and w1.shape[1] == ATT and w1.shape[0] % 32 == 0:
+                if bf16 in ("bf16", "f16", True) and not os.environ.get("TOUCAN_NO_FUSED_FFN") and (w1.ndim == 2 or w1.shape[2] == 1) and w1.shape[1] == ATT and w1.shape[0] % 32 == 0:
                     blk[ff + ".fused"] = packing.pack_ffn(w1, sd[p + ff + ".w_1.bias"], sd[p + ff + ".w_2.weight"], device, "f16" if bf16 == "f16" else "bf16")
             a = p + "self_attn."
             wqkv = np.concatenate([sd[a + f"linear_{n}.weight"] for n in "qkv"], axis=0)
@@ -397,7 +409,7 @@ class AcousticEngine:
         self.ops = None if pack_only else Ops(device)
         self.device = torch.device(device) if pack_only else self.ops.device
         self.precision, bf16, compute16, self.dt16 = precision_of(bf16, precision)
-        self.bf16 = bool(bf16)  # a 16-bit MFMA configuration (either format)
+        self.bf16 = bf16 in ("bf16", "f16", True)  # a 16-bit MFMA configuration (either format); "x3" keeps fp32 tensors
         self.use_graphs = use_graphs
         self._graphs = GraphCache(self.device)
         if bf16 and self.ops is not None:
@@ -520,7 +532,7 @@ class AcousticEngine:
                 ops.conv(blk["feed_forward_macaron.w2"], hid, x, rag, alpha=0.5, res=x)
             ops.layernorm(x, ln, *blk["norm_mha"], R, ATT)
             ops.conv(blk["qkv"], ln, qkv, rag)
-            ops.attention(qkv, cw.ptabs[li], cw.pmax, blk["u"], blk["v"], ctx, rag, f16=self.precision != "f32" and not NO_F16_ATTENTION)
+            ops.attention(qkv, cw.ptabs[li], cw.pmax, blk["u"], blk["v"], ctx, rag, f16=self.bf16 and not NO_F16_ATTENTION)
             ops.conv(blk["out"], ctx, x, rag, res=x)
             ops.layernorm(x, ln, *blk["norm_conv"], R, ATT)
             ops.conv(blk["pw1"], ln, glu, rag)
@@ -789,7 +801,8 @@ class VocoderEngine:
         # variant needs 111-131 VGPRs and loses occupancy, so the stand-alone kernel is the default for now.
         self.fuse_snake = fuse_snake
         # 16-bit modes only: one fused kernel per residual dilation step (tts_resblock_step) for the stages with C <= 128
-        self.fuse_step = bool(bf16) if fuse_step is None else bool(fuse_step and bf16)
+        is16 = bf16 in ("bf16", "f16", True)  # ("x3": fp32 tensors, unfused path, every conv on the split fp32 product)
+        self.fuse_step = is16 if fuse_step is None else bool(fuse_step and is16)
         # C = 256 (stage 1) is supported by the fused kernel too, but with one 4-wave workgroup per CU it only ties the
         # unfused convs + stand-alone snakes (9.1 vs 9.0 ms per step measured), so stage 1 keeps the unfused path
         self.fuse_max_channels = 128

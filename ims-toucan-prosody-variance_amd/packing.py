@@ -85,10 +85,19 @@ class ConvWeights:
         else:
             packed[:, :cin, : self.cout] = w_kio
         self.w = torch.from_numpy(packed).to(device)
-        # optional 16-bit copy for the bf16 / fp16 MFMA paths: `bf16` is False, True / "bf16", or "f16" (one format per conv)
+        # optional 16-bit copy for the bf16 / fp16 MFMA paths: `bf16` is False, True / "bf16", "f16" or "x3" (one format per conv)
         self.w16 = None
         self.compute16 = capi.COMPUTE_F32
-        if bf16:
+        if bf16 == "x3":
+            # the split fp32 product (TTS_COMPUTE_F32X3): two fp16 planes [hi | lo'], hi = fp16(w), lo' = fp16((w - hi) 2^11), each in
+            # the 16-bit fragment layout below
+            self.compute16 = capi.COMPUTE_F32X3
+            t32 = torch.from_numpy(packed)
+            hi = t32.to(torch.float16)
+            lo = ((t32 - hi.to(torch.float32)) * 2048.0).to(torch.float16)
+            frag = lambda t: t.reshape(taps, self.cin_pad // 8, 8, self.wn).permute(0, 1, 3, 2).contiguous()
+            self.w16 = torch.cat([frag(hi), frag(lo)], dim=0).contiguous().to(device)  # [2 taps][cin_pad/8][wn][8]: the hi plane, then the lo' plane
+        elif bf16:
             dt = torch.float16 if bf16 == "f16" else torch.bfloat16
             self.compute16 = capi.COMPUTE_F16 if bf16 == "f16" else capi.COMPUTE_BF16
             # [taps][cin_pad/8][wn][8]: a B fragment (8 consecutive k for one column) is one 16-byte read

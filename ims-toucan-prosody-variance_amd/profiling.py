@@ -17,7 +17,7 @@ def kernel_class(cw, compute, tile_rows=None):
     bm, bn = cw.tile_rows, cw.n_tile
     if tile_rows is not None and tile_rows != cw.tile_rows:
         bm, bn = tile_rows, 64
-    prec = {capi.COMPUTE_F32: "f32", capi.COMPUTE_BF16: "bf16", capi.COMPUTE_F16: "f16"}[compute]
+    prec = {capi.COMPUTE_F32: "f32", capi.COMPUTE_BF16: "bf16", capi.COMPUTE_F16: "f16", capi.COMPUTE_F32X3: "f32x3"}[compute]
     return "conv1d_%s<%dx%d%s>" % (prec, bm, bn, ",dual" if dual else "")
 
 

@@ -65,6 +65,9 @@ typedef struct {
 #define TTS_COMPUTE_F32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation */
 #define TTS_COMPUTE_BF16 1 /* v_mfma_f32_32x32x16_bf16, fp32 accumulation (BASELINE.json configs[2]) */
 #define TTS_COMPUTE_F16 2  /* v_mfma_f32_32x32x16_f16, fp32 accumulation (BASELINE.json configs[4]) */
+#define TTS_COMPUTE_F32X3 3 /* fp32 tensors, every product as three fp16 matrix instructions on split operands (hi.hi + 2^-11 (hi.lo' + lo'.hi),
+                               fp32 accumulation): ~22 significant bits per product at 16/3 of the fp32 matrix rate.  tts_conv1d only; its
+                               16-bit weight argument then holds the two fp16 planes [hi | lo'] of [tap][cin_pad/8][wn][8] */
 #define TTS_PRE_NONE 0
 #define TTS_PRE_LRELU 1
 #define TTS_PRE_SNAKE 2 /* anti-aliased SnakeBeta (see tts_snake_aa) applied while the input window is staged */

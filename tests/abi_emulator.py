@@ -148,7 +148,11 @@ class Emulator:
         dual = d.mode != capi.MODE_LINEAR
         f16 = bool(d.io_flags & capi.IO_F16) or d.compute == capi.COMPUTE_F16
         fx, fy, fr = (_fmt(d.io_flags & b, f16) for b in (capi.IO_X_BF16, capi.IO_Y_BF16, capi.IO_RES_BF16))
-        if d.compute != capi.COMPUTE_F32:
+        if d.compute == capi.COMPUTE_F32X3:  # two fp16 planes [hi | lo']: w = hi + 2^-11 lo' (what the three products add up to)
+            wraw = _arr(d.w, 2 * d.taps * d.cin_pad * d.wn, np.uint16).reshape(2, d.taps, d.cin_pad // 8, d.wn, 8)
+            planes = [_widen16(wraw[i], True).reshape(wraw[i].shape).transpose(0, 1, 3, 2).reshape(d.taps, d.cin_pad, d.wn).astype(np.float64) for i in (0, 1)]
+            w = planes[0] + planes[1] / 2048.0
+        elif d.compute != capi.COMPUTE_F32:
             wraw = _arr(d.w, d.taps * d.cin_pad * d.wn, np.uint16).reshape(d.taps, d.cin_pad // 8, d.wn, 8)
             w = _widen16(wraw, d.compute == capi.COMPUTE_F16).reshape(wraw.shape).transpose(0, 1, 3, 2).reshape(d.taps, d.cin_pad, d.wn)
         else:
@@ -162,10 +166,13 @@ class Emulator:
             elif d.pre_act == capi.PRE_SNAKE:
                 x = _snake_seq(x.astype(np.float64), _arr(d.snake_alpha, d.cin), _arr(d.snake_beta, d.cin),
                                _arr(d.snake_filt, 12)).astype(np.float32)
-            if d.compute != capi.COMPUTE_F32:
+            if d.compute == capi.COMPUTE_F32X3:  # x = hi + 2^-11 lo' with the same two fp16 roundings as the kernel
+                hi = _round16(x, True)
+                x = hi.astype(np.float64) + _round16(((x - hi) * np.float32(2048.0)).astype(np.float32), True).astype(np.float64) / 2048.0
+            elif d.compute != capi.COMPUTE_F32:
                 x = _round16(x, d.compute == capi.COMPUTE_F16)
             halo = (d.taps - 1) * d.dil
-            xp = np.zeros((n + halo, d.cin), dtype=np.float32)
+            xp = np.zeros((n + halo, d.cin), dtype=np.float64 if d.compute == capi.COMPUTE_F32X3 else np.float32)
             xp[d.pad_left:d.pad_left + n] = x
             acc = np.zeros((n, d.wn), dtype=np.float64)
             for j in range(d.taps):

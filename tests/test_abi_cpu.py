@@ -37,7 +37,7 @@ def test_binding_and_header_agree():
     # geometry helpers are host-side (no GPU needed)
     assert lib.tts_conv1d_tile_rows(192, capi.MODE_LINEAR) in (128, 256)
     assert lib.tts_conv1d_small_tile_rows(192, capi.MODE_LINEAR, 192) == 64
-    assert lib.tts_resblock_tile_rows(64) == 224 and lib.tts_conv_post_snake_tile_rows() == 250
+    assert lib.tts_resblock_tile_rows(64) == 480 and lib.tts_resblock_tile_rows(128) == 224 and lib.tts_conv_post_snake_tile_rows() == 250
     assert lib.tts_cln_mlp_weight_floats(64, 256) == 64 * 64 + 64 + 64 * 256 + 256 + 256 * 256 + 256
 
 

@@ -38,10 +38,11 @@ def close(a, b, tol=2e-5):
     assert err <= tol * scale, f"max abs err {err:.3e} vs tol {tol * scale:.3e}"
 
 
-PACK16 = {capi.COMPUTE_F32: True, capi.COMPUTE_BF16: "bf16", capi.COMPUTE_F16: "f16"}  # pack_conv's 16-bit copy per compute mode
+PACK16 = {capi.COMPUTE_F32: True, capi.COMPUTE_BF16: "bf16", capi.COMPUTE_F16: "f16", capi.COMPUTE_F32X3: "x3"}  # pack_conv's 16-bit copy per compute mode
 DT16 = {capi.COMPUTE_BF16: torch.bfloat16, capi.COMPUTE_F16: torch.float16}
-TOL = {capi.COMPUTE_F32: 2e-5, capi.COMPUTE_BF16: 2e-2, capi.COMPUTE_F16: 3e-3}  # relative to the output scale
-ALL_COMPUTE = [capi.COMPUTE_F32, capi.COMPUTE_BF16, capi.COMPUTE_F16]
+# relative to the output scale (F32X3: the split fp32 product - ~22 bits per product, fp32 accumulation: the fp32 tolerance holds)
+TOL = {capi.COMPUTE_F32: 2e-5, capi.COMPUTE_BF16: 2e-2, capi.COMPUTE_F16: 3e-3, capi.COMPUTE_F32X3: 2e-5}
+ALL_COMPUTE = [capi.COMPUTE_F32, capi.COMPUTE_BF16, capi.COMPUTE_F16, capi.COMPUTE_F32X3]
 
 
 def both(gpu, cpu, fn):
@@ -217,7 +218,7 @@ def test_conv1d_split_k_always_is_independent_of_the_grid(gpu, cpu):
 
 
 @pytest.mark.parametrize("c,k,dil,lengths", [(32, 3, 1, [1000, 9, 257]), (64, 11, 5, [300, 40]), (256, 7, 3, [130, 1, 2]), (128, 3, 5, [64, 8])])
-@pytest.mark.parametrize("compute", ALL_COMPUTE)
+@pytest.mark.parametrize("compute", ALL_COMPUTE[:3])  # (the snake prologue does not exist for the split fp32 product)
 def test_conv1d_with_fused_antialiased_snake(gpu, cpu, c, k, dil, lengths, compute):
     """TTS_PRE_SNAKE: the conv's input staging applies Activation1d(SnakeBeta) (AMP.py:53-56) - ragged edges included."""
     w = rnd(c, c, k, seed=1, scale=1.0 / np.sqrt(c * k)).numpy()
@@ -776,3 +777,35 @@ def test_graph_replay_beside_eager_residual_steps_on_another_stream(gpu):
             for got_g, got_e, w in zip(g_out, e_out, want):
                 assert torch.equal(got_g[rows], w[rows]) and torch.equal(got_e[rows], w[rows])
     assert lib.tts_diag_queue_slots_used() == used0 + 1 + 3 + 1, "eager launches of a stream reuse its slot"
+
+
+@pytest.mark.parametrize("cin,cout,k,mode,rows", [(192, 1536, 1, capi.MODE_LINEAR, 4096), (1536, 192, 1, capi.MODE_LINEAR, 4096),
+                                                  (192, 384, 5, capi.MODE_GATED, 2048), (256, 256, 5, capi.MODE_LINEAR, 3000)])
+def test_split_fp32_product_is_as_close_to_float64_as_the_fp32_kernel(gpu, cin, cout, k, mode, rows):
+    """TTS_COMPUTE_F32X3 (three fp16 MFMAs on split operands, fp32 accumulation) against a float64 product of the same fp32
+    operands, beside the exact fp32 kernel: its error stays within 4x the fp32 kernel's (22 vs 24 bits per product; the
+    accumulation is fp32 in both), far inside the 16-bit modes' - on operands of mixed magnitude (incl. values below fp16's
+    normal range, which the scaled low plane still carries)."""
+    w = rnd(cout, cin, k, seed=1, scale=1.0 / np.sqrt(cin * k)).numpy()
+    dual = mode != capi.MODE_LINEAR
+    co = cout // 2 if dual else cout
+    rag = Ragged([rows], gpu.device, align=2)
+    x = rnd(rows, cin, seed=3) * torch.logspace(-5, 1.5, cin)[None, :]  # per-channel magnitudes 1e-5 .. 30
+    xd = x.to("cuda:0").contiguous()
+    outs = {}
+    gpu.small_tile_blocks = 0
+    try:
+        for compute in (capi.COMPUTE_F32, capi.COMPUTE_F32X3, capi.COMPUTE_F16):
+            cw = packing.pack_conv(w, None, gpu.device, mode=capi.MODE_LINEAR, bf16=PACK16[compute])
+            y = torch.zeros(rows, cout, device="cuda:0")
+            gpu.conv(cw, xd, y, rag, compute=compute)
+            outs[compute] = y.cpu().double()
+    finally:
+        gpu.small_tile_blocks = 1536
+    xp = torch.zeros(rows + k - 1, cin, dtype=torch.float64)
+    xp[(k - 1) // 2:(k - 1) // 2 + rows] = x.double()
+    ref = sum(xp[j:j + rows] @ torch.from_numpy(w[:, :, j].T.astype(np.float64)) for j in range(k))
+    scale = float(ref.abs().max())
+    e32, ex3, e16 = (float((outs[c] - ref).abs().max()) / scale for c in (capi.COMPUTE_F32, capi.COMPUTE_F32X3, capi.COMPUTE_F16))
+    print(f"max error / output scale: fp32 {e32:.2e}, split fp32 {ex3:.2e}, fp16 {e16:.2e}")
+    assert ex3 < max(4 * e32, 2e-6) and ex3 < 1e-2 * e16 + 2e-6
