@@ -9,7 +9,7 @@
 //
 // Both products run transposed (weights are the MFMA A operand, accumulator row = output channel, lane = frame), so epilogues
 // work on float4 / packed 8-byte pieces of a frame's row (see resblock.hip).  Weights stream as 32-channel slabs (24 KB) through
-// a THREE-deep LDS ring filled by direct global->LDS loads (global_load_lds_dwordx4): no staging registers, two slabs in flight
+// a WN_RING-deep LDS ring filled by direct global->LDS loads (global_load_lds_dwordx4): no staging registers, WN_RING - 1 slabs in flight
 // across the raw s_barrier of a step, counted s_waitcnt vmcnt (cdna_hip_programming.md, "Pipelining across barriers" - this
 // kernel runs at one workgroup per CU and one wavefront per SIMD, the regime where that matters).
 #include "common.h"
@@ -25,13 +25,17 @@ constexpr int WN_KS = 32;            // channels per weight slab
 constexpr int WN_SLAB_BYTES = (WN_KS / 8) * 384 * 16;  // 24 KB: [4][384][8] 16-bit
 constexpr int WN_SLABS1 = WN_TAPS * (WN_H / WN_KS);    // 30 slab steps of the gated conv
 constexpr int WN_SLABS2 = WN_H / WN_KS;                // 6 of the res/skip conv
+// LDS ring slots: WN_RING - 1 slabs in flight (five slots = 120 KB of the CU's 160: a global -> LDS load lands ~1.1 us after it is
+// issued, a slab step takes ~0.9 us)
+constexpr int WN_RING = 5;
+constexpr int WN_LOADS = 6;                            // global_load_lds instructions per wavefront and slab (narrow slabs re-request units)
 }  // namespace
 
 template <bool F16>
 __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   unsigned short* xs = reinterpret_cast<unsigned short*>(lds_raw);                       // [68][XP] window of h, later [64][XP] acts
-  unsigned char* ring = lds_raw + ((WN_BM + WN_TAPS - 1) * WN_XP * 2 + 255) / 256 * 256;  // [3][24 KB]
+  unsigned char* ring = lds_raw + ((WN_BM + WN_TAPS - 1) * WN_XP * 2 + 255) / 256 * 256;  // [WN_RING][24 KB]
   const TtsTile tile = d.tiles[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, lrow = lane & 31, lk = lane >> 5;
   const int n2 = d.cout2;                       // 384 or 192
@@ -40,33 +44,33 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
   const char* w1 = reinterpret_cast<const char*>(d.w1);
   const char* w2 = reinterpret_cast<const char*>(d.w2);
 
-  // direct global -> LDS copy of weight slab s into ring[s % 3]: wave w moves units i*256 + w*64 + lane (1 KB per instruction)
-  auto issue = [&](int s) __attribute__((always_inline)) {
+  // direct global -> LDS copy of weight slab s into ring[s % WN_RING]: wave w moves units i*256 + w*64 + lane (1 KB per instruction).
+  // Every slab is WN_LOADS instructions per wavefront (a narrow res/skip slab re-requests its last units), so the number of loads
+  // in flight behind a slab is a compile-time constant.  One piece = one instruction per wavefront; a step spreads the pieces of
+  // the slab it requests between its matrix instructions (issued in a block in front of them, each piece held the wavefront's
+  // issue for 100+ cycles - MI355X_MICROARCH.md, "LDS-DMA piece issue cost": 38.2 -> 34.9 us per layer)
+  auto issue_piece = [&](int s, int i) __attribute__((always_inline)) {
+    if (s >= total) return;
     const bool second = s >= WN_SLABS1;
     const int units = second ? units2 : (WN_KS / 8) * 384;
     const char* src = second ? w2 + (size_t)(s - WN_SLABS1) * units2 * 16 : w1 + (size_t)s * WN_SLAB_BYTES;  // slabs are contiguous: [tap][k/8][n][8]
-    unsigned char* dst = ring + (size_t)(s % 3) * WN_SLAB_BYTES;
+    unsigned char* dst = ring + (size_t)(s % WN_RING) * WN_SLAB_BYTES;
 #ifdef WN_DIAG_NO_DMA  // (timing diagnostics only: no weight traffic, results are wrong)
-    if (s > 2) return;
+    if (s >= WN_RING) return;
 #endif
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int u0 = i * 256 + wave * 64;
-      if (u0 < units)
-        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)(u0 + lane) * 16),
-                                         (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 16), 16, 0, 0);
-    }
+    const int u0 = i * 256 + wave * 64;
+    int u = u0 + lane;
+    u = u < units ? u : units - 1;
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + (size_t)u * 16),
+                                     (void __attribute__((address_space(3)))*)(dst + (size_t)u0 * 16), 16, 0, 0);
   };
-  auto loads_of = [&](int s) __attribute__((always_inline)) {  // global_load_lds instructions THIS wave issues for slab s
-    if (s >= total) return 0;
-    const int units = s >= WN_SLABS1 ? units2 : (WN_KS / 8) * 384;
-    int n = 0;
-    for (int i = 0; i < 6; ++i) n += (i * 256 + wave * 64 < units) ? 1 : 0;
-    return n;
+  auto issue = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WN_LOADS; ++i) issue_piece(s, i);
   };
 
-  issue(0);  // the first two weight slabs land while the window is staged
-  issue(1);
+#pragma unroll
+  for (int i = 0; i < WN_RING - 1; ++i) issue(i);  // the first slabs land while the window is staged (total = 36 >= WN_RING - 1)
   // ---- window of the hidden state: rows row0 - 2 .. row0 + 65 (zero outside the utterance = the conv's zero padding) -> 16-bit
   {
     // PER independent 16-byte loads per thread are in flight before the first is consumed (clamped addresses, no branches): one
@@ -100,12 +104,14 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-  auto wait_for = [&](int s) __attribute__((always_inline)) {  // slab s has landed; the loads of slab s + 1 may stay in flight
-    const int keep = loads_of(s + 1);
-    if (keep >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (keep >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  // slab s has landed; the loads of the slabs behind it (min(WN_RING - 2, slabs left) x WN_LOADS) may stay in flight
+  auto wait_for = [&](int s) __attribute__((always_inline)) {
+    const int behind = total - 1 - s;  // slabs requested behind s so far: min(behind, WN_RING - 2)
+    static_assert(WN_RING >= 3 && WN_RING <= 6, "one wait per number of slabs in flight below");
+    if (WN_RING >= 6 && behind >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * WN_LOADS) : "memory");
+    else if (WN_RING >= 5 && behind >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * WN_LOADS) : "memory");
+    else if (WN_RING >= 4 && behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * WN_LOADS) : "memory");
+    else if (behind >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WN_LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS stores (window / acts) are done before the barrier publishes them
     __builtin_amdgcn_s_barrier();
@@ -114,9 +120,8 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
   // ---- gated conv: acc[0..2] = a, acc[3..5] = g for channels wn*96 + j*32 ..; frames wm*32 ..
   for (int s = 0; s < WN_SLABS1; ++s) {
     wait_for(s);
-    if (s + 2 < total) issue(s + 2);
     const int tap = s / (WN_H / WN_KS), k0 = (s % (WN_H / WN_KS)) * WN_KS;
-    const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % 3) * WN_SLAB_BYTES);
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % WN_RING) * WN_SLAB_BYTES);
     // all fragments of the step first (14 LDS reads in flight), then the 12 MFMAs: with one wavefront per SIMD nothing else hides
     // an LDS round trip in front of every MFMA, which is what the compiler's own interleaving produced
     bf16x8 xf[WN_KS / 16], wf[WN_KS / 16][6];
@@ -134,8 +139,15 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
 #pragma unroll
     for (int kk = 0; kk < WN_KS / 16; ++kk)
 #pragma unroll
-      for (int j = 0; j < 6; ++j) acc[j] = mfma16<F16>(wf[kk][j], xf[kk], acc[j]);
+      for (int j = 0; j < 6; ++j) {
+        if ((kk * 6 + j) % 2 == 0) {  // one piece of the slab WN_RING - 1 steps ahead per two matrix instructions
+          issue_piece(s + WN_RING - 1, (kk * 6 + j) / 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[j] = mfma16<F16>(wf[kk][j], xf[kk], acc[j]);
+      }
 #else
+    issue(s + WN_RING - 1);
     for (int j = 0; j < 6; ++j) acc[j][0] += bf16_to_f32(wf[0][j][0]) + bf16_to_f32(xf[1][1]) + bf16_to_f32(wf[1][j][2]);
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -176,9 +188,8 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
   const int half2 = n2 >> 1, nj = n2 >> 6;
   for (int s = WN_SLABS1; s < total; ++s) {
     wait_for(s);  // (also publishes acts on the first step)
-    if (s + 2 < total) issue(s + 2);
     const int k0 = (s - WN_SLABS1) * WN_KS;
-    const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % 3) * WN_SLAB_BYTES);
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(ring + (size_t)(s % WN_RING) * WN_SLAB_BYTES);
     bf16x8 xf[WN_KS / 16], wf[WN_KS / 16][6];
 #pragma unroll
     for (int kk = 0; kk < WN_KS / 16; ++kk) {
@@ -193,8 +204,13 @@ __global__ __launch_bounds__(256) void wavenet_layer_kernel(const TtsWavenetDesc
 #pragma unroll
     for (int kk = 0; kk < WN_KS / 16; ++kk)
 #pragma unroll
-      for (int j = 0; j < 6; ++j)
+      for (int j = 0; j < 6; ++j) {
+        if ((kk * 6 + j) % 2 == 0) {
+          issue_piece(s + WN_RING - 1, (kk * 6 + j) / 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (j < nj) acc[j] = mfma16<F16>(wf[kk][j], xf[kk], acc[j]);
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- [h | skip] out = in + res_skip + bias (last layer: the skip half only)
@@ -231,7 +247,7 @@ int wavenet_layer(const TtsWavenetDesc& d, hipStream_t st) {
                     ((uintptr_t)d.b2 & 15) == 0,
                 "wavenet_layer: rows and weights must be 16-byte aligned");
   if (d.n_tiles == 0) return TTS_OK;
-  const size_t lds = ((size_t)(WN_BM + WN_TAPS - 1) * WN_XP * 2 + 255) / 256 * 256 + 3 * (size_t)WN_SLAB_BYTES;
+  const size_t lds = ((size_t)(WN_BM + WN_TAPS - 1) * WN_XP * 2 + 255) / 256 * 256 + WN_RING * (size_t)WN_SLAB_BYTES;
   static unsigned long long raised[2] = {0, 0};
   const bool f16 = d.compute == TTS_COMPUTE_F16;
   const void* k = f16 ? reinterpret_cast<const void*>(wavenet_layer_kernel<true>) : reinterpret_cast<const void*>(wavenet_layer_kernel<false>);
