@@ -142,6 +142,7 @@ PROTOTYPES = {
     "tts_load_weights": (C.c_int, [_p, C.c_char_p, _p, C.POINTER(C.c_int64), _i, _i]),
     "tts_workspace_bytes": (C.c_int64, [_p, _i, _i, _i]),
     "tts_workspace_claimed": (C.c_int64, [_p]),
+    "tts_table_stats": (C.c_int, [_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tts_encoder": (C.c_int, [_p, _p, _p, _p, _p, _i, _p]),
     "tts_variance_predictors": (C.c_int, [_p, _p, _p, _p, _p]),
     "tts_control_and_regulate": (C.c_int, [_p, _f, _f, _f, _f, _p, _p]),

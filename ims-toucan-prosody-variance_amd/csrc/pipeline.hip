@@ -18,6 +18,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "common.h"
@@ -93,6 +94,21 @@ struct TileTab {
   int n = 0;
 };
 
+// Tile tables / utterance bounds of ONE batch's group of stages (acoustic stages, or the vocoder): pinned host staging and the device
+// copy, filled by asynchronous copies on the group's stream - no device allocation, no synchronisation per table.  Two generations
+// per group alternate from batch to batch.
+struct TableArena {
+  char* dev = nullptr;
+  char* host = nullptr;
+  size_t cap = 0, off = 0;
+  hipEvent_t copied = nullptr;   // recorded behind the generation's latest copy: the staging bytes may be rewritten once it has passed
+  hipEvent_t fence = nullptr;    // (reuse from another stream) everything enqueued on the previous stream when the arena is taken again
+  bool armed = false;
+  hipStream_t stream = nullptr;  // the stream the generation's copies and kernels were enqueued on
+  std::unordered_map<std::string, TileTab> tiles;
+  std::unordered_map<std::string, int*> bounds;
+};
+
 // one timed launch of the roofline leg (tts_profile): HIP events on the launch stream around a matrix-core kernel
 struct ProfRec {
   std::string name;
@@ -107,8 +123,16 @@ struct Handle {
   std::unordered_map<std::string, Dev> weights;
   bool resolved = false;
   Arena phone, frame, voc[2], tables;
+  // tables of layouts that keep coming back (a benchmark's fixed batch): device allocations of their own, kept.  A layout is
+  // built into the batch's TableArena the first time it is seen and moves here the second time (real traffic - new utterance
+  // lengths every batch - never allocates or synchronises for a table).
   std::unordered_map<std::string, TileTab> tile_cache;
   std::unordered_map<std::string, int*> bounds_cache;
+  std::unordered_set<std::string> seen_once;
+  TableArena tabs[2][2];          // [0: acoustic stages, 1: vocoder][generation]
+  int tab_gen[2] = {0, 0};
+  int tab_which = 0;              // group of the stage entry that runs (set with split_mode)
+  long long n_arena_tables = 0, n_cached_tables = 0;  // tables built into a batch arena / given a permanent allocation (tts_table_stats)
   int small_tile_blocks = 1536;
   int split_mode = 0;             // set by the stage entries; the fp32 configuration only.  2 (phoneme stages: encoder, predictors): split-K convs
                                   // and key-split attention at EVERY grid size - durations are a rounding of exp(log d), so everything upstream
@@ -200,6 +224,69 @@ void drop_tables(Handle* h) {
   h->bounds_cache.clear();
 }
 
+// a stage group starts a batch: take the group's other table generation
+int tables_begin(Handle* h, int which, hipStream_t st) {
+  h->tab_which = which;
+  h->tab_gen[which] ^= 1;
+  TableArena& a = h->tabs[which][h->tab_gen[which]];
+  if (a.armed) {
+    // the staging bytes of the batch before last: its copies have long run unless the host is more than two batches ahead of the GPU
+    TTS_TRY(hip_ok(hipEventSynchronize(a.copied), "tile tables: staging buffer still in flight"));
+    if (a.stream != st) {  // its kernels ran on another stream: order this batch's copies behind everything enqueued there
+      TTS_TRY(hip_ok(hipEventRecord(a.fence, a.stream), "tile tables: fence"));
+      TTS_TRY(hip_ok(hipStreamWaitEvent(st, a.fence, 0), "tile tables: fence wait"));
+    }
+  }
+  a.off = 0;
+  a.stream = st;
+  a.tiles.clear();
+  a.bounds.clear();
+  return TTS_OK;
+}
+
+// bytes -> the current generation of the running group (staging copy + one asynchronous upload); *dev_out: the device address
+int table_put(Handle* h, const void* data, size_t bytes, hipStream_t st, void** dev_out) {
+  TableArena& a = h->tabs[h->tab_which][h->tab_gen[h->tab_which]];
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (a.off + need > a.cap) {  // (rare: the first batches, or a batch far larger than any before)
+    // tables already handed out from this generation are still referenced by launches in flight: nothing may be freed under them
+    TTS_TRY(hip_ok(hipDeviceSynchronize(), "tile tables: sync before regrowth"));
+    const size_t cap = std::max<size_t>(std::max<size_t>(a.cap * 2, a.off + need), (size_t)4 << 20);
+    char *dev = nullptr, *host = nullptr;
+    TTS_TRY(hip_ok(hipMalloc(reinterpret_cast<void**>(&dev), cap), "tile tables: hipMalloc"));
+    TTS_TRY(hip_ok(hipHostMalloc(reinterpret_cast<void**>(&host), cap, hipHostMallocDefault), "tile tables: hipHostMalloc"));
+    if (a.off) {
+      memcpy(host, a.host, a.off);
+      TTS_TRY(hip_ok(hipMemcpy(dev, a.dev, a.off, hipMemcpyDeviceToDevice), "tile tables: regrowth copy"));
+      // (tables of this generation handed out before the regrowth keep their old addresses: rebuild the maps' pointers)
+      for (auto& kv : a.tiles) kv.second.dev = reinterpret_cast<TtsTile*>(dev + (reinterpret_cast<char*>(kv.second.dev) - a.dev));
+      for (auto& kv : a.bounds) kv.second = reinterpret_cast<int*>(dev + (reinterpret_cast<char*>(kv.second) - a.dev));
+    }
+    if (a.dev) (void)hipFree(a.dev);
+    if (a.host) (void)hipHostFree(a.host);
+    a.dev = dev; a.host = host; a.cap = cap;
+  }
+  if (!a.copied) {
+    TTS_TRY(hip_ok(hipEventCreateWithFlags(&a.copied, hipEventDisableTiming), "tile tables: event"));
+    TTS_TRY(hip_ok(hipEventCreateWithFlags(&a.fence, hipEventDisableTiming), "tile tables: event"));
+  }
+  memcpy(a.host + a.off, data, bytes);
+  TTS_TRY(hip_ok(hipMemcpyAsync(a.dev + a.off, a.host + a.off, bytes, hipMemcpyHostToDevice, st), "tile tables: upload"));
+  TTS_TRY(hip_ok(hipEventRecord(a.copied, st), "tile tables: event record"));
+  a.armed = true;
+  *dev_out = a.dev + a.off;
+  a.off += need;
+  return TTS_OK;
+}
+
+// first sighting of a layout: build into the batch arena; second sighting: it is a repeating layout - give it a permanent table
+bool repeating(Handle* h, const std::string& key) {
+  if (h->seen_once.count(key)) return true;
+  if (h->seen_once.size() > 8192) h->seen_once.clear();
+  h->seen_once.insert(key);
+  return false;
+}
+
 int tiles_of(Handle* h, const Layout& l, int tile_rows, hipStream_t st, TileTab* out) {
   const std::string key = layout_key(l, tile_rows);
   auto it = h->tile_cache.find(key);
@@ -207,22 +294,38 @@ int tiles_of(Handle* h, const Layout& l, int tile_rows, hipStream_t st, TileTab*
     *out = it->second;
     return TTS_OK;
   }
-  if (h->tile_cache.size() > 512) {  // (no launch in flight may still read a table - on this stream or, when the caller runs the
-                                     // vocoder of one batch beside the acoustic model of the next, on another: drain the device first)
-    (void)st;
-    TTS_TRY(hip_ok(hipDeviceSynchronize(), "tile tables: sync before trimming the cache"));
-    drop_tables(h);
+  TableArena& a = h->tabs[h->tab_which][h->tab_gen[h->tab_which]];
+  auto ia = a.tiles.find(key);
+  if (ia != a.tiles.end()) {
+    *out = ia->second;
+    return TTS_OK;
   }
   std::vector<TtsTile> host;
   for (int u = 0; u < l.n(); ++u)
     for (int r = 0; r < l.lengths[u]; r += tile_rows) host.push_back(TtsTile{l.begins[u] + r, l.begins[u], l.begins[u] + l.lengths[u], u});
   TileTab t;
   t.n = (int)host.size();
+  if (!repeating(h, key)) {
+    if (host.empty()) host.push_back(TtsTile{0, 0, 0, 0});
+    void* dev;
+    TTS_TRY(table_put(h, host.data(), host.size() * sizeof(TtsTile), st, &dev));
+    t.dev = static_cast<TtsTile*>(dev);
+    a.tiles[key] = t;
+    ++h->n_arena_tables;
+    *out = t;
+    return TTS_OK;
+  }
+  if (h->tile_cache.size() > 512) {  // (no launch in flight may still read a table - on this stream or, when the caller runs the
+                                     // vocoder of one batch beside the acoustic model of the next, on another: drain the device first)
+    TTS_TRY(hip_ok(hipDeviceSynchronize(), "tile tables: sync before trimming the cache"));
+    drop_tables(h);
+  }
   TTS_TRY(hip_ok(hipMalloc(reinterpret_cast<void**>(&t.dev), std::max<size_t>(1, host.size()) * sizeof(TtsTile)), "tile table: hipMalloc"));
   if (!host.empty())
     TTS_TRY(hip_ok(hipMemcpyAsync(t.dev, host.data(), host.size() * sizeof(TtsTile), hipMemcpyHostToDevice, st), "tile table: upload"));
-  TTS_TRY(hip_ok(hipStreamSynchronize(st), "tile table: upload sync"));  // (the host vector goes out of scope; tables are built once per layout)
+  TTS_TRY(hip_ok(hipStreamSynchronize(st), "tile table: upload sync"));  // (the host vector goes out of scope; once per repeating layout)
   h->tile_cache[key] = t;
+  ++h->n_cached_tables;
   *out = t;
   return TTS_OK;
 }
@@ -232,18 +335,28 @@ int bounds_of(Handle* h, const Layout& l, hipStream_t st, const int** sb, const 
   const std::string key = layout_key(l, -1);
   auto it = h->bounds_cache.find(key);
   int* dev = nullptr;
+  TableArena& a = h->tabs[h->tab_which][h->tab_gen[h->tab_which]];
   if (it != h->bounds_cache.end()) {
     dev = it->second;
+  } else if (a.bounds.count(key)) {
+    dev = a.bounds[key];
   } else {
     std::vector<int> host(2 * std::max(1, l.n()));
     for (int u = 0; u < l.n(); ++u) {
       host[u] = l.begins[u];
       host[l.n() + u] = l.begins[u] + l.lengths[u];
     }
-    TTS_TRY(hip_ok(hipMalloc(reinterpret_cast<void**>(&dev), host.size() * sizeof(int)), "bounds: hipMalloc"));
-    TTS_TRY(hip_ok(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, st), "bounds: upload"));
-    TTS_TRY(hip_ok(hipStreamSynchronize(st), "bounds: upload sync"));
-    h->bounds_cache[key] = dev;
+    if (!repeating(h, key)) {
+      void* p;
+      TTS_TRY(table_put(h, host.data(), host.size() * sizeof(int), st, &p));
+      dev = static_cast<int*>(p);
+      a.bounds[key] = dev;
+    } else {
+      TTS_TRY(hip_ok(hipMalloc(reinterpret_cast<void**>(&dev), host.size() * sizeof(int)), "bounds: hipMalloc"));
+      TTS_TRY(hip_ok(hipMemcpyAsync(dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice, st), "bounds: upload"));
+      TTS_TRY(hip_ok(hipStreamSynchronize(st), "bounds: upload sync"));
+      h->bounds_cache[key] = dev;
+    }
   }
   *sb = dev;
   *se = dev + l.n();
@@ -638,6 +751,13 @@ int pipeline_destroy(Handle* h) {
     if (kv.second.dtype != 3 && kv.second.p) (void)hipFree(kv.second.p);
     else free(kv.second.p);
   drop_tables(h);
+  for (auto& group : h->tabs)
+    for (TableArena& t : group) {
+      if (t.dev) (void)hipFree(t.dev);
+      if (t.host) (void)hipHostFree(t.host);
+      if (t.copied) (void)hipEventDestroy(t.copied);
+      if (t.fence) (void)hipEventDestroy(t.fence);
+    }
   for (Arena* a : {&h->phone, &h->frame, &h->voc[0], &h->voc[1]})
     if (a->base) (void)hipFree(a->base);
   for (int s = 0; s < 2; ++s)
@@ -703,6 +823,7 @@ int pipeline_encoder(Handle* h, const float* text, const float* utt_emb, const i
   TTS_CHECK_ARG(h && text && phone_lengths && B > 0, "tts_encoder: bad arguments");
   TTS_CHECK_ARG(!h->cfg.multispeaker || utt_emb, "tts_encoder: the multi-speaker checkpoint needs utterance embeddings");
   h->split_mode = 2;
+  TTS_TRY(tables_begin(h, 0, st));  // a batch starts: its tile tables go to the acoustic stages' other generation
   h->lp = Layout::make(phone_lengths, B, 1);
   h->B = B;
   h->text = text;
@@ -771,6 +892,7 @@ int pipeline_encoder(Handle* h, const float* text, const float* utt_emb, const i
 int pipeline_predictors(Handle* h, const float* gold_pitch, const float* gold_energy, const int* gold_dur, hipStream_t st) {
   TTS_CHECK_ARG(h && h->enc, "tts_variance_predictors: run tts_encoder first");
   h->split_mode = 2;
+  h->tab_which = 0;
   const int R = h->lp.total, B = h->B;
   Arena& a = h->phone;
   if (h->cfg.multispeaker && !(gold_pitch && gold_energy && gold_dur)) {
@@ -801,6 +923,7 @@ int pipeline_control_regulate(Handle* h, float duration_scale, float pitch_scale
                               int* frames_out, hipStream_t st) {
   TTS_CHECK_ARG(h && h->enc && h->dur, "tts_control_and_regulate: run tts_encoder and tts_variance_predictors first");
   TTS_CHECK_ARG(duration_scale > 0.f, "tts_control_and_regulate: duration_scaling_factor must be positive");
+  h->tab_which = 0;
   const int R = h->lp.total, B = h->B;
   const int *pb, *pe;
   TTS_TRY(bounds_of(h, h->lp, st, &pb, &pe));
@@ -839,6 +962,7 @@ int pipeline_control_regulate(Handle* h, float duration_scale, float pitch_scale
 int pipeline_decoder(Handle* h, hipStream_t st) {
   TTS_CHECK_ARG(h && h->dec, "tts_decoder: run tts_control_and_regulate first");
   h->split_mode = 1;
+  h->tab_which = 0;
   TTS_TRY(conformer(h, 1, h->dec, h->lf, h->frame, st));
   ConvW fo;
   TTS_TRY(conv_of(h, "feat_out", &fo));
@@ -852,6 +976,7 @@ int pipeline_decoder(Handle* h, hipStream_t st) {
 int pipeline_postnet(Handle* h, hipStream_t st) {
   TTS_CHECK_ARG(h && h->mel0, "tts_postnet: run tts_decoder first");
   h->split_mode = 1;
+  h->tab_which = 0;
   const Layout& l = h->lf;
   const int RF = l.total;
   Arena& a = h->frame;
@@ -893,6 +1018,7 @@ int pipeline_postflow(Handle* h, const float* z_noise, hipStream_t st) {
   TTS_CHECK_ARG(h && h->mel == h->cat && h->cat, "tts_postflow: run tts_postnet first");
   TTS_CHECK_ARG(z_noise, "tts_postflow: z_noise is required");
   h->split_mode = 1;
+  h->tab_which = 0;
   const Layout ls = h->lf.halved();
   const int RF = h->lf.total, RS = RF / 2;
   Arena& a = h->frame;
@@ -988,6 +1114,7 @@ int pipeline_vocoder(Handle* h, int kind, const float* mel, int ld_mel, const in
   TTS_CHECK_ARG(h && mel && frame_begins && frame_counts && wav && B > 0, "tts_vocoder: bad arguments");
   TTS_CHECK_ARG(kind == h->cfg.vocoder, "tts_vocoder: the handle was created for vocoder %d, not %d", h->cfg.vocoder, kind);
   h->split_mode = 0;
+  TTS_TRY(tables_begin(h, 1, st));
   const bool big = kind == 2;
   Layout l;
   for (int u = 0; u < B; ++u) {
@@ -1158,6 +1285,12 @@ int64_t tts_workspace_bytes(const TtsHandle* h, int32_t B, int32_t Lmax, int32_t
   return tts::pipeline_workspace_bytes(reinterpret_cast<const tts::Handle*>(h), B, Lmax, Tmax);
 }
 int64_t tts_workspace_claimed(const TtsHandle* h) { return tts::pipeline_workspace_claimed(reinterpret_cast<const tts::Handle*>(h)); }
+int tts_table_stats(const TtsHandle* h, int64_t* arena_tables, int64_t* cached_tables) {
+  if (!h || !arena_tables || !cached_tables) return TTS_E_ARG;
+  *arena_tables = reinterpret_cast<const tts::Handle*>(h)->n_arena_tables;
+  *cached_tables = reinterpret_cast<const tts::Handle*>(h)->n_cached_tables;
+  return TTS_OK;
+}
 int tts_encoder(TtsHandle* h, const float* text, const float* utt_emb, const int32_t* lang_ids, const int32_t* phone_lengths, int32_t B,
                 tts_stream_t stream) {
   return tts::pipeline_encoder(H(h), text, utt_emb, lang_ids, phone_lengths, B, ST(stream));

@@ -398,11 +398,11 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   // conv2 of the previous tile; before the weight and constant loads for the first tile) - its memory latency never shows.
   constexpr int Q8 = C / 8;
   constexpr int PERX = !MFIR ? 1 : (IOB ? (C == 128 ? 11 : (C == 64 ? 6 : 3)) : 4);
-  // one-tile-ahead prefetch into registers: C = 128 only (one workgroup per CU, 256 registers per lane).  C <= 64 runs two
-  // workgroups per CU on 128 registers: there the next image is only pulled towards the L2 (l2_prefetch below) and loaded at the
-  // top of its tile.  fp32 x would need twice the registers: loaded in place.
+  // one-tile-ahead prefetch into registers: C = 128 only (one workgroup per CU, 256 registers per lane).  C <= 64 and fp32 x
+  // load the image at the top of its tile.  (Round 2 pulled the next image towards the L2 with one 4-byte touch per line: the
+  // counters showed every touched line fetched twice - FETCH_SIZE 1.7-1.8 x algorithmic for C = 64 - and no time gained;
+  // without it 1.04-1.05 x at the same speed, profiles/r03_pmc_resblock_traffic.json.)
   constexpr bool XPF = MFIR && IOB && C == 128;
-  constexpr bool L2PF = MFIR && !XPF;
   const int img_units = img_rows * Q8;
   uint4 xv[PERX], xv2[(MFIR && !IOB) ? PERX : 1];
   auto stage_issue = [&](const TtsTile& tl, int base) __attribute__((always_inline)) {
@@ -466,25 +466,6 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   }
   TtsTile tile = load_tile(cur_tile);
   if (XPF && snake) stage_issue(tile, tid);
-  // one 4-byte load per 128-byte line of the next tile's image: the line is in this XCD's L2 when the tile starts.  Ordinary
-  // loads into NPF registers that stay allocated until conv2 is over, where a dummy use retires them - the compiler
-  // tracks them like any load.  (A global -> LDS load needs no register, but every later LDS access then waits for it: measured
-  // 2.5 k cycles at the next ds_read.)  Issued unconditionally (without a next tile: the current one's lines) - a value defined
-  // on one side of a branch only is what the register allocator spills first.
-  constexpr int L2_ROW_BYTES = C * (IOB ? 2 : 4), L2_LPR = (L2_ROW_BYTES + 127) / 128, NPF = L2PF ? L2_LPR : 1;
-  auto l2_prefetch = [&](const TtsTile& tl, int tid_, unsigned int (&sink)[NPF]) __attribute__((always_inline)) {
-    const int Tn = tl.seq_end - tl.seq_begin, fr0 = tl.row0 - tl.seq_begin - RB_LEAD - h1 - PADR;
-    const int n_lines = (win_rows + 2 * PADR) * L2_LPR;
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-      int e = tid_ + k * RB_THREADS;
-      e = e < n_lines ? e : n_lines - 1;
-      const int t = fr0 + e / L2_LPR;
-      const int tc = t < 0 ? 0 : (t > Tn - 1 ? Tn - 1 : t);
-      const char* ptr = reinterpret_cast<const char*>(d.x) + ((size_t)(tl.seq_begin + tc) * d.ldx) * (IOB ? 2 : 4) + (e % L2_LPR) * 128;
-      sink[k] = *reinterpret_cast<const unsigned int*>(ptr);  // (not volatile: a volatile load is followed by vmcnt(0); the dummy use keeps it)
-    }
-  };
 
   if constexpr (DMA) {
     dma_issue(0, 0, tid);
@@ -540,9 +521,6 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     ticket_drawn = true;
     if (tid == 0) ticket_raw = atomicAdd(&queue[xcc], 1u);
   }
-  unsigned int pf_sink[NPF];
-#pragma unroll
-  for (int k = 0; k < NPF; ++k) pf_sink[k] = 0;
   const int T = tile.seq_end - tile.seq_begin;
   const int l0 = tile.row0 - tile.seq_begin;  // local frame of the tile's first output row
   RB_STAMP(0);
@@ -776,9 +754,6 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
     tile_next.seq_end = __builtin_amdgcn_readfirstlane(e.z);
     tile_next.seq_id = __builtin_amdgcn_readfirstlane(e.w);
   }
-  if constexpr (L2PF) {
-    if (snake) l2_prefetch(tile_next, tid, pf_sink);
-  }
   if (MFIR && snake) {
     if constexpr (MFIR) {
       // act2 in place on t1 (rows [0, M1) of the window; the 6 rows on either side only feed outputs conv2 never reads)
@@ -941,10 +916,6 @@ __global__ __launch_bounds__(RbCfg<C>::THREADS, (C == 32 ? RB_C32_WAVES : (C == 
   RB_SETPRIO(RB_PRIO_BASE);
 
   if (has_next) rb_barrier();  // every wavefront is done reading t1 and the slab ring: the next tile's image may overwrite them
-  if constexpr (L2PF) {
-#pragma unroll
-    for (int k = 0; k < NPF; ++k) asm volatile("" ::"v"(pf_sink[k]));  // (the L2 prefetch loads retire here)
-  }
   RB_STAMP(8);
   // ------------------------------------------------------------------ epilogue
   // transposed accumulators again: lane = output row, registers = groups of four consecutive channels.  Residual read, scaling,

@@ -106,11 +106,12 @@ class ToucanTTSInterface(torch.nn.Module):
         sd = _to_numpy_sd(checkpoint["model"])
         # variant detection: the reference retries load_state_dict (:55-63); the schema tells us directly
         self.use_lang_id = "encoder.language_embedding.weight" in sd
-        # precision of the MFMA GEMMs: fp32 (exact-parity default), TOUCAN_PRECISION=bf16 / f16 (BASELINE.json configs[2] / [4]), or
-        # TOUCAN_PRECISION=mixed: acoustic model in fp32 (the mel keeps exact parity), vocoder on the fp16 matrix cores
+        # precision of the MFMA GEMMs: fp32 (exact-parity default), TOUCAN_PRECISION=bf16 / f16 (BASELINE.json configs[2] / [4]),
+        # f32x3 (fp32 tensors, dense products as three fp16 MFMAs on split operands: keeps the fp32 tolerances), or mixed / mixed3:
+        # acoustic model in fp32 / f32x3 (the mel keeps the fp32 parity), vocoder on the fp16 matrix cores
         precision = os.environ.get("TOUCAN_PRECISION", "f32")
-        voc_precision = "f16" if precision == "mixed" else precision
-        precision = "f32" if precision == "mixed" else precision
+        voc_precision = "f16" if precision in ("mixed", "mixed3") else precision
+        precision = {"mixed": "f32", "mixed3": "f32x3"}.get(precision, precision)
         voc = _load_checkpoint(vocoder_model_path)
         voc_sd, kind = _to_numpy_sd(voc["generator"]), "hifigan" if faster_vocoder else "bigvgan"
         # On a GPU the whole pass runs through the stage API (native.NativePipeline -> csrc/pipeline.hip: the kernels are sequenced in
@@ -232,7 +233,8 @@ class ToucanTTSInterface(torch.nn.Module):
     def synthesize_batch(self, texts, input_is_phones=True, utterance_embeddings=None, z_noise=None, durations=None, pitch=None,
                          energy=None, duration_scaling_factor=1.0, pitch_variance_scale=1.0, energy_variance_scale=1.0,
                          pause_duration_scaling_factor=1.0, distributed=False):
-        """Additive API: a ragged batch in one pass; each utterance equals the reference run on it alone.
+        """Additive API: a ragged batch in one pass; each utterance equals the reference run on it alone (16-bit configurations: bit
+        for bit whatever the batch; fp32: durations / pitch / energy bit for bit, the mel to fp32 rounding order - DESIGN.md section 4).
         texts: phoneme strings (or [L,62] feature tensors).  durations / pitch / energy: optional per-utterance gold prosody (the
         cloner-style call, UtteranceCloner.py:163).  With ``distributed=True`` and an initialised process group the utterances are
         dealt over the ranks by frame count and every rank returns all waveforms (distributed.py)."""

@@ -216,6 +216,15 @@ class NativePipeline:
         """Upper bound (bytes) of the workspace a batch of that shape will claim - what a caller budgets HBM from."""
         return sum(int(self.lib.tts_workspace_bytes(handle, B, Lmax, Tmax)) for handle in self._handles())
 
+    def table_stats(self):
+        """(tile tables built into batch arenas, tile tables given a permanent allocation) over this pipeline's handles."""
+        a = b = 0
+        for handle in self._handles():
+            x, y = C.c_int64(), C.c_int64()
+            capi.check(self.lib.tts_table_stats(handle, C.byref(x), C.byref(y)), "tts_table_stats")
+            a, b = a + x.value, b + y.value
+        return a, b
+
     def workspace_claimed(self):
         """Bytes the handles' arenas hold right now."""
         return sum(int(self.lib.tts_workspace_claimed(handle)) for handle in self._handles())

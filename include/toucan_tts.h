@@ -353,6 +353,10 @@ int tts_load_weights(TtsHandle* h, const char* name, const void* host_ptr, const
 int64_t tts_workspace_bytes(const TtsHandle* h, int32_t B, int32_t Lmax, int32_t Tmax);
 /* Bytes the handle's workspace arenas hold right now (after a batch: what that batch - and every larger one before it - claimed). */
 int64_t tts_workspace_claimed(const TtsHandle* h);
+/* Tile tables the handle has built so far: into a batch's table arena (stream-ordered copies, no allocation, no synchronisation:
+ * every layout the first time it is seen) / with a permanent device allocation (a layout seen a second time: a benchmark's fixed
+ * batch).  Real traffic - new utterance lengths in every batch - only ever counts in the first. */
+int tts_table_stats(const TtsHandle* h, int64_t* arena_tables, int64_t* cached_tables);
 
 /* text: packed phoneme features [sum L, 62]; utt_emb [B, 64] (NULL for the single-speaker variant); lang_ids [B] (NULL: no
  * language embedding); phone_lengths: host [B].  Starts a batch: later stages work on the handle's state. */

@@ -60,7 +60,7 @@ def test_descriptor_layouts_match_the_header():
         assert fields == [f[0] for f in cls._fields_], struct
 
 
-STAGE_API = {"tts_create", "tts_destroy", "tts_load_weights", "tts_workspace_bytes", "tts_workspace_claimed", "tts_encoder", "tts_variance_predictors",
+STAGE_API = {"tts_create", "tts_destroy", "tts_load_weights", "tts_workspace_bytes", "tts_workspace_claimed", "tts_table_stats", "tts_encoder", "tts_variance_predictors",
              "tts_control_and_regulate", "tts_decoder", "tts_postnet", "tts_postflow", "tts_mel", "tts_copy_mel", "tts_prosody",
              "tts_copy_prosody", "tts_profile", "tts_profile_count", "tts_profile_read", "tts_vocoder_bigvgan", "tts_vocoder_hifigan", "tts_synthesize_batch"}
 

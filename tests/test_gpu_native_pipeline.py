@@ -228,3 +228,48 @@ def test_mixed_precision_pipeline_is_the_fp32_acoustic_model_plus_the_fp16_vocod
     for (b0, n), (b1, n1) in zip(out["wav_spans"], zip(rag.begins, rag.lengths)):
         assert n == n1 and torch.equal(out["wav"][b0:b0 + n], wav[b1:b1 + n1])
     assert mixed.workspace_bytes(4, 128, 640) > 0
+
+
+def test_new_layouts_never_allocate_or_synchronise_for_their_tile_tables():
+    """Real traffic: every batch has utterance lengths never seen before.  Twelve such batches through the two-stream pipeline: all
+    their tile tables go through the per-batch table arenas (pinned staging + stream-ordered copies: tts_table_stats counts no
+    permanent table for a length-dependent layout), and every result equals the Python sequencer's (own tables, own path) bit for bit.  The second time a layout
+    comes by it is promoted to a permanent table (a benchmark's fixed batch) - and still gives the same bits."""
+    ac_sd, voc_sd = fw.acoustic_state_dict(), fw.hifigan_state_dict()
+    pipe = native.NativePipeline(ac_sd, voc_sd, "hifigan", DEV)
+    ac, voc = engine.AcousticEngine(ac_sd, DEV), engine.VocoderEngine(voc_sd, "hifigan", DEV)
+    batches = []
+    for k in range(12):
+        Ls = [9 + 5 * k + 3 * u for u in range(1 + k % 3)]
+        feats = [torch.from_numpy(syn.utterance_features(800 + 10 * k + u, L)) for u, L in enumerate(Ls)]
+        embs = torch.from_numpy(np.stack([syn.utterance_embedding(800 + 10 * k + u) for u in range(len(Ls))]))
+        durs = [torch.from_numpy(syn.ragged_durations(800 + 10 * k + u, f.numpy())) for u, f in enumerate(feats)]
+        zs = [torch.from_numpy(syn.postflow_noise(800 + 10 * k + u, int(d.sum()))) for u, d in enumerate(durs)]
+        batches.append(dict(texts=feats, utt_embs=embs, lang_ids=[syn.LANG_EN] * len(Ls), durations=durs, z_noise=zs))
+    want = []
+    for kw in batches:
+        ref = ac.forward(kw["texts"], kw["utt_embs"], kw["lang_ids"], durations=kw["durations"], z_noise=kw["z_noise"])
+        w, rw = voc.forward(ref["mel_packed"], ref["rag_mel"])
+        want.append(([m.clone() for m in ref["mel"]], [w[b0:b0 + n].clone() for b0, n in zip(rw.begins, rw.lengths)]))
+    torch.cuda.synchronize()
+    a0, c0 = pipe.table_stats()
+    got = list(pipe.forward_pipelined(batches))
+    torch.cuda.synchronize()
+    a1, c1 = pipe.table_stats()
+    # every length-dependent table through an arena; the only layouts that come by twice are the one-row-per-utterance ones of
+    # the 1-, 2- and 3-utterance batches (utterance-embedding projections, two tile heights): those are promoted, nothing else
+    assert a1 - a0 >= 12 * 6 and c1 - c0 <= 6, (a0, c0, a1, c1)
+    for out, (mels, wavs) in zip(got, want):
+        for m_got, m_want in zip(out["mel"], mels):
+            assert torch.equal(m_got, m_want)
+        for (b0, n), w_want in zip(out["wav_spans"], wavs):
+            assert torch.equal(out["wav"][b0:b0 + n], w_want)
+    again = list(pipe.forward_pipelined(batches[:3]))  # second sighting: permanent tables
+    torch.cuda.synchronize()
+    a2, c2 = pipe.table_stats()
+    assert c2 > c1
+    for out, (mels, wavs) in zip(again, want[:3]):
+        for m_got, m_want in zip(out["mel"], mels):
+            assert torch.equal(m_got, m_want)
+        for (b0, n), w_want in zip(out["wav_spans"], wavs):
+            assert torch.equal(out["wav"][b0:b0 + n], w_want)

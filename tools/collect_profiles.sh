@@ -15,6 +15,8 @@ python3 $R/bench.py --vocoder hifigan --no-cpu-baseline > $O/bench_bf16_hifigan.
 python3 $R/bench.py --sequencer python --no-cpu-baseline > $O/bench_bf16_python_sequencer.json 2>/dev/null
 python3 $R/bench.py --no-overlap --no-cpu-baseline > $O/bench_bf16_one_stream.json 2>/dev/null
 python3 $R/bench.py --dtype mixed --no-cpu-baseline > $O/bench_mixed_f32_f16.json 2>/dev/null
+python3 $R/bench.py --dtype mixed3 --no-cpu-baseline > $O/bench_mixed3_f32x3_f16.json 2>/dev/null
+python3 $R/bench.py --dtype fp32x3 --no-cpu-baseline > $O/bench_fp32x3.json 2>/dev/null
 python3 $R/tools/latency_configs.py > $O/latency_configs.jsonl 2>/dev/null
 python3 $R/tools/stage_times.py > $O/stage_times_bf16.txt 2>/dev/null
 python3 $R/tools/stage_times.py --batch 1 --precision f32 > $O/stage_times_b1_f32.txt 2>/dev/null
@@ -35,8 +37,12 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_w -o r -
 cp /tmp/p_w/*counter_collection.csv $O/pmc_resblock_WRITE_SIZE.csv
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/p_sq -o r -- python3 $R/tools/microbench_resblock.py --store bf16 --reps 2 > $O/pmc_sq.log 2>&1
 cp /tmp/p_sq/*counter_collection.csv $O/pmc_resblock_SQ.csv
+echo "[collect] second SQ pass (co-execution, LDS)"; date
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS --kernel-trace --output-format csv -d /tmp/p_sq2 -o r -- python3 $R/tools/microbench_resblock.py --store bf16 --reps 2 > $O/pmc_sq2.log 2>&1
+cp /tmp/p_sq2/*counter_collection.csv $O/pmc_resblock_SQ2.csv
+python3 $R/tools/pmc_dump.py $O/pmc_resblock_SQ2.csv resblock > $O/pmc_sq2_dump.txt
 python3 $R/tools/pmc_traffic.py $O/pmc_resblock_FETCH_SIZE.csv $O/pmc_resblock_WRITE_SIZE.csv $O/pmc_resblock_traffic.json > $O/pmc_traffic_summary.txt
 python3 $R/tools/pmc_sq_summary.py $O/pmc_resblock_SQ.csv $O/pmc_resblock_SQ_summary.json > $O/pmc_sq_summary.txt
 python3 $R/tools/microbench_resblock.py --store bf16 --reps 5 > $O/microbench_resblock_bf16.txt 2>/dev/null
-rm -f $O/pmc_fetch.log $O/pmc_write.log $O/pmc_sq.log $O/rocprof_bf16.log $O/rocprof_fp16.log $O/rocprof_b1.log
+rm -f $O/pmc_fetch.log $O/pmc_write.log $O/pmc_sq.log $O/pmc_sq2.log $O/rocprof_bf16.log $O/rocprof_fp16.log $O/rocprof_b1.log
 echo "[collect] done"; date
