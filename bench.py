@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--pitch-scale", type=float, default=1.0, help="pitch_variance_scale (configs[4]: 1.3)")
     ap.add_argument("--energy-scale", type=float, default=1.0, help="energy_variance_scale (configs[4]: 0.7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the B = 1 check run after the timed region (kernel traces: its short launches would dilute the averages)")
     ap.add_argument("--fuse-snake", action="store_true", help="BigVGAN: anti-aliased snake inside the conv input staging")
     ap.add_argument("--graphs", action="store_true", help="replay the shape-static stages as HIP graphs (no per-kernel roofline leg)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -544,7 +546,7 @@ def main():
             line["cpu_baseline"], oracle_out = cpu_baseline(L, args.frames_per_phone, args.vocoder, scales)
         else:
             oracle_out = None
-        if use_native:
+        if use_native and not args.no_verify:
             log("verify: utterance 0 of the last timed step against a B = 1 run" + (" and the CPU oracle" if oracle_out else ""))
             line["verify"] = verify_against_single_run(pipe, last_out, last_wav, packed, z_sq, scales, B, oracle_out)
         print(json.dumps(line))

@@ -24,11 +24,11 @@ python3 $R/tools/microbench_small.py > $O/microbench_small_f32.txt 2>/dev/null
 python3 $R/tools/conv_shapes.py > $O/conv_shapes_bf16.txt 2>/dev/null
 python3 $R/tools/microbench_ffn.py > $O/microbench_ffn_bf16.txt 2>/dev/null
 echo "[collect] kernel traces"; date
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bf16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $O/rocprof_bf16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bf16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-verify > $O/rocprof_bf16.log 2>&1
 cp /tmp/p_bf16/*kernel_stats.csv $O/bench_bf16_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b1 -o r -- python3 $R/tools/latency_configs.py --reps 5 > $O/rocprof_b1.log 2>&1
 cp /tmp/p_b1/*kernel_stats.csv $O/latency_configs_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fp16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --dtype fp16 --pitch-scale 1.3 --energy-scale 0.7 > $O/rocprof_fp16.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_fp16 -o r -- python3 $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-verify --dtype fp16 --pitch-scale 1.3 --energy-scale 0.7 > $O/rocprof_fp16.log 2>&1
 cp /tmp/p_fp16/*kernel_stats.csv $O/bench_fp16_kernel_stats.csv
 echo "[collect] counter passes (separate runs, --kernel-trace only)"; date
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_f -o r -- python3 $R/tools/microbench_resblock.py --store bf16 --reps 2 > $O/pmc_fetch.log 2>&1

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--graphs", action="store_true", help="replay the pass as HIP graphs (fixed shapes; python sequencer)")
     ap.add_argument("--sequencer", default="native", choices=["native", "python"])
+    ap.add_argument("--only-configs1", action="store_true", help="configs[1] alone (for a kernel trace of that pass)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     use_native = args.sequencer == "native" and not args.graphs
@@ -60,6 +61,8 @@ def main():
     t = timeit(run1, args.reps)
     print(json.dumps({"config": "configs[1]: batch=1 x 128 phonemes, acoustic fp32, mel only", "graphs": args.graphs, "sequencer": tag,
                       "abi_calls": calls, "ms": 1e3 * t, "mel_frames_per_s": 5 * L / t}))
+    if args.only_configs1:
+        return
 
     L = 20
     text = [torch.from_numpy(syn.utterance_features(1, L)).to(dev)]
