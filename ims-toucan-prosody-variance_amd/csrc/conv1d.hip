@@ -30,6 +30,10 @@
 #include "common.h"
 #include "snake.h"
 
+#ifndef CONV_DIAG
+#define CONV_DIAG 0  // diagnostic builds of conv1d_kernel (tools/build_variant.sh NAME -DCONV_DIAG=n): 1 no epilogue, 2 no MFMAs, 3 window staged for slab 0 only, 4 weight slab loaded once
+#endif
+
 namespace tts {
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL>
@@ -88,32 +92,44 @@ struct Elem<false, F16> {
   static __device__ __forceinline__ float cvt(float v) { return v; }
 };
 
-// One output element of the fused epilogue: a / g are the raw accumulators (g: the gate half in the dual modes), ba / bg the
-// biases, sv the per-utterance vector.  Shared by the 32 x 32 and the 16 x 16 accumulator layouts.
+// One output element of the fused epilogue, up to the store: a / g are the raw accumulators (g: the gate half in the dual modes),
+// ba / bg the biases, sv the per-utterance vector, pa / pg the pre-add, ax the coupling input, rv the residual.  Shared by every
+// accumulator layout, so all of them round alike.
 template <bool DUAL>
-__device__ __forceinline__ void epilogue_element(const TtsConvDesc& d, int row, int n, float a, float g, float ba, float bg, float sv, bool io_f16) {
+__device__ __forceinline__ float epilogue_value(const TtsConvDesc& d, float a, float g, float ba, float bg, float sv, float pa, float pg, float ax,
+                                                float rv) {
   float v = a + ba + sv;
-  if (d.preadd) v += d.preadd[(size_t)row * d.ld_preadd + n];
+  if (d.preadd) v += pa;
   if (DUAL) {
     g += bg;
-    if (d.preadd) g += d.preadd[(size_t)row * d.ld_preadd + d.cout + n];
+    if (d.preadd) g += pg;
     if (d.mode == TTS_MODE_GLU) {
       v = v * (1.0f / (1.0f + expf(-g)));
     } else if (d.mode == TTS_MODE_GATED) {
       v = tanhf(v) * (1.0f / (1.0f + expf(-g)));
     } else {  // COUPLING
-      v = (d.aux[(size_t)row * d.ld_aux + n] - v) * expf(-g);
+      v = (ax - v) * expf(-g);
     }
   } else {
     if (d.act == TTS_ACT_RELU) v = fmaxf(v, 0.0f);
     else if (d.act == TTS_ACT_TANH) v = tanhf(v);
   }
   v *= d.alpha;
-  if (d.res) {
-    const float rv = (d.io_flags & TTS_IO_RES_BF16) ? load16(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n], io_f16)
-                                                    : d.res[(size_t)row * d.ld_res + n];
-    v += d.res_scale * rv;
-  }
+  if (d.res) v += d.res_scale * rv;
+  return v;
+}
+
+// ... one element at a time (the layouts whose lanes hold single columns, and the ragged right edge of the others)
+template <bool DUAL>
+__device__ __forceinline__ void epilogue_element(const TtsConvDesc& d, int row, int n, float a, float g, float ba, float bg, float sv, bool io_f16) {
+  const float pa = d.preadd ? d.preadd[(size_t)row * d.ld_preadd + n] : 0.0f;
+  const float pg = (DUAL && d.preadd) ? d.preadd[(size_t)row * d.ld_preadd + d.cout + n] : 0.0f;
+  const float ax = (DUAL && d.mode == TTS_MODE_COUPLING) ? d.aux[(size_t)row * d.ld_aux + n] : 0.0f;
+  float rv = 0.0f;
+  if (d.res)
+    rv = (d.io_flags & TTS_IO_RES_BF16) ? load16(reinterpret_cast<const unsigned short*>(d.res)[(size_t)row * d.ld_res + n], io_f16)
+                                        : d.res[(size_t)row * d.ld_res + n];
+  float v = epilogue_value<DUAL>(d, a, g, ba, bg, sv, pa, pg, ax, rv);
   if (d.io_flags & TTS_IO_Y_BF16) {
     unsigned short* yp = reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n;
     if (d.accumulate) v += load16(*yp, io_f16);
@@ -122,6 +138,94 @@ __device__ __forceinline__ void epilogue_element(const TtsConvDesc& d, int row, 
     float* yp = d.y + (size_t)row * d.ldy + n;
     if (d.accumulate) v += *yp;
     *yp = v;
+  }
+}
+
+// Can the epilogue move four consecutive columns of a row at a time?  (every tensor it touches: 16-byte (fp32) / 8-byte (16-bit)
+// aligned base, leading dimension and half offset a multiple of four)
+__device__ __forceinline__ bool epilogue_vec_ok(const TtsConvDesc& d) {
+  auto al = [](const void* p, unsigned m) { return (reinterpret_cast<uintptr_t>(p) & (m - 1)) == 0; };
+  bool ok = (d.cout & 3) == 0 && (d.ldy & 3) == 0 && al(d.y, (d.io_flags & TTS_IO_Y_BF16) ? 8 : 16);
+  if (d.bias) ok = ok && al(d.bias, 16);
+  if (d.seqvec) ok = ok && (d.ld_seqvec & 3) == 0 && al(d.seqvec, 16);
+  if (d.preadd) ok = ok && (d.ld_preadd & 3) == 0 && al(d.preadd, 16);
+  if (d.res) ok = ok && (d.ld_res & 3) == 0 && al(d.res, (d.io_flags & TTS_IO_RES_BF16) ? 8 : 16);
+  if (d.mode == TTS_MODE_COUPLING) ok = ok && (d.ld_aux & 3) == 0 && al(d.aux, 16);
+  return ok;
+}
+
+// Epilogue of a TRANSPOSED 32x32 accumulator (weights were the MFMA A operand): row of the tile = lane&31, column =
+// (reg&3) + 8*(reg>>2) + 4*(lane>>5) - a lane owns four groups of four consecutive output channels of ONE row, so bias, pre-add,
+// residual, accumulate and the store move 8 (16-bit tensors) or 16 (fp32) bytes at a time.  (With the output channel on the lane -
+// the untransposed layout - a 128 x 128 tile left through 64 two-byte stores per lane: 58 us of a 147 us launch at 256 -> 256
+// channels x 3 taps, 122 of 211 us with a residual read the same way, 340 of 609 us in the 128 -> 256 up-sampler; measured with
+// -DCONV_DIAG=1.)  A row's pieces are written by one wavefront within a few hundred cycles: L2 merges them into whole lines.
+template <int TM, int TN, int NH, bool DUAL>
+__device__ __forceinline__ void conv_epilogue_t(const TtsConvDesc& d, const TtsTile& tile, int n0, int wm, int wn, int lrow, int lk,
+                                                const f32x16 (&acc)[NH][TM][TN]) {
+  const bool io_f16 = d.io_flags & TTS_IO_F16;  // format of the 16-bit tensors of this call (else bf16)
+  const bool vec = epilogue_vec_ok(d);
+  const bool y16 = d.io_flags & TTS_IO_Y_BF16, r16 = d.io_flags & TTS_IO_RES_BF16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = tile.row0 + (wm * TM + i) * 32 + lrow;
+    if (row >= tile.seq_end) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = n0 + (wn * TN + j) * 32 + 8 * rq + 4 * lk;
+        if (n >= d.cout) continue;
+        if (!vec) {
+          for (int q = 0; q < 4 && n + q < d.cout; ++q) {
+            const float ba = d.bias ? d.bias[n + q] : 0.0f;
+            const float bg = (DUAL && d.bias) ? d.bias[d.cout + n + q] : 0.0f;
+            const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n + q] : 0.0f;
+            epilogue_element<DUAL>(d, row, n + q, acc[0][i][j][4 * rq + q], acc[NH - 1][i][j][4 * rq + q], ba, bg, sv, io_f16);
+          }
+          continue;
+        }
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+        const float4 ba = d.bias ? ld4(d.bias + n) : z4;
+        const float4 bg = (DUAL && d.bias) ? ld4(d.bias + d.cout + n) : z4;
+        const float4 sv = d.seqvec ? ld4(d.seqvec + (size_t)tile.seq_id * d.ld_seqvec + n) : z4;
+        const float4 pa = d.preadd ? ld4(d.preadd + (size_t)row * d.ld_preadd + n) : z4;
+        const float4 pg = (DUAL && d.preadd) ? ld4(d.preadd + (size_t)row * d.ld_preadd + d.cout + n) : z4;
+        const float4 ax = (DUAL && d.mode == TTS_MODE_COUPLING) ? ld4(d.aux + (size_t)row * d.ld_aux + n) : z4;
+        float4 rv = z4;
+        if (d.res) {
+          if (r16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(d.res) + (size_t)row * d.ld_res + n);
+            rv = make_float4(load16(u.x & 0xFFFF, io_f16), load16(u.x >> 16, io_f16), load16(u.y & 0xFFFF, io_f16), load16(u.y >> 16, io_f16));
+          } else {
+            rv = ld4(d.res + (size_t)row * d.ld_res + n);
+          }
+        }
+        float v[4];
+        v[0] = epilogue_value<DUAL>(d, acc[0][i][j][4 * rq + 0], acc[NH - 1][i][j][4 * rq + 0], ba.x, bg.x, sv.x, pa.x, pg.x, ax.x, rv.x);
+        v[1] = epilogue_value<DUAL>(d, acc[0][i][j][4 * rq + 1], acc[NH - 1][i][j][4 * rq + 1], ba.y, bg.y, sv.y, pa.y, pg.y, ax.y, rv.y);
+        v[2] = epilogue_value<DUAL>(d, acc[0][i][j][4 * rq + 2], acc[NH - 1][i][j][4 * rq + 2], ba.z, bg.z, sv.z, pa.z, pg.z, ax.z, rv.z);
+        v[3] = epilogue_value<DUAL>(d, acc[0][i][j][4 * rq + 3], acc[NH - 1][i][j][4 * rq + 3], ba.w, bg.w, sv.w, pa.w, pg.w, ax.w, rv.w);
+        if (y16) {
+          uint2* yp = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n);
+          if (d.accumulate) {
+            const uint2 u = *yp;
+            v[0] += load16(u.x & 0xFFFF, io_f16); v[1] += load16(u.x >> 16, io_f16);
+            v[2] += load16(u.y & 0xFFFF, io_f16); v[3] += load16(u.y >> 16, io_f16);
+          }
+          *yp = make_uint2((unsigned int)store16(v[0], io_f16) | ((unsigned int)store16(v[1], io_f16) << 16),
+                           (unsigned int)store16(v[2], io_f16) | ((unsigned int)store16(v[3], io_f16) << 16));
+        } else {
+          float4* yp = reinterpret_cast<float4*>(d.y + (size_t)row * d.ldy + n);
+          if (d.accumulate) {
+            const float4 u = *yp;
+            v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+          }
+          *yp = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
   }
 }
 
@@ -365,6 +469,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
     const int kchunk = (d.cin_pad - c0) < BK ? (d.cin_pad - c0) : BK;
     ET* xs = xs0 + ((win2 && (ch & 1)) ? xs_elems : 0);
     if (!win2 && ch > 0) __syncthreads();  // the previous slab's MFMAs are done with xs
+#if CONV_DIAG == 3
+    if (ch == 0) {
+#endif
     // ---- stage the activation window: win_rows x kchunk channels, through the input activation ----
     if (win2) {
       // already in LDS (committed at the end of the previous slab); request the next one now, it lands under this slab's MFMAs
@@ -508,10 +615,17 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
         }
       }
     }
+#if CONV_DIAG == 3
+    }
+#endif
     for (int tap = 0; tap < d.taps; ++tap, ++step) {
       __syncthreads();  // xs and ws[step&1] visible; everybody is done reading ws[(step+1)&1]
       const bool more = step + 1 < total_steps;
+#if CONV_DIAG == 4
+      if (false) {
+#else
       if (more) {
+#endif
         const int ntap = tap + 1 < d.taps ? tap + 1 : 0;
         const int nc0 = tap + 1 < d.taps ? c0 : c0 + BK;
         const int nk = (d.cin_pad - nc0) < BK ? (d.cin_pad - nc0) : BK;
@@ -539,10 +653,14 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
-                acc[h][i][j] = mfma16<F16>(a[i], b[j], acc[h][i][j]);
+#if CONV_DIAG == 2
+                asm volatile("" ::"v"(a[i]), "v"(b[j]));
+#else
+                acc[h][i][j] = mfma16<F16>(b[j], a[i], acc[h][i][j]);  // transposed: weights = A operand, the lane keeps a ROW (conv_epilogue_t)
+#endif
                 if constexpr (X3) {
-                  accx[h][i][j] = mfma16<true>(a[i], bl[j], accx[h][i][j]);
-                  accx[h][i][j] = mfma16<true>(al[i], b[j], accx[h][i][j]);
+                  accx[h][i][j] = mfma16<true>(bl[j], a[i], accx[h][i][j]);
+                  accx[h][i][j] = mfma16<true>(b[j], al[i], accx[h][i][j]);
                 }
               }
           }
@@ -565,7 +683,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j)
-                acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[h][i][j], 0, 0, 0);
+                acc[h][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j], a[i], acc[h][i][j], 0, 0, 0);
           }
         }
       }
@@ -586,7 +704,20 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[h][i][j][r] = fmaf(accx[h][i][j][r], 1.0f / 2048.0f, acc[h][i][j][r]);
   }
-  conv_epilogue<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
+#if CONV_DIAG == 1
+  {  // diagnostic build: no epilogue (one never-taken store keeps the accumulators alive)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[0][i][j][r];
+    if (t == 1.2345e-30f) d.y[0] = t;
+  }
+#else
+  conv_epilogue_t<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
