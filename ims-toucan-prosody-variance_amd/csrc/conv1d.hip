@@ -31,7 +31,7 @@
 #include "snake.h"
 
 #ifndef CONV_DIAG
-#define CONV_DIAG 0  // diagnostic builds of conv1d_kernel (tools/build_variant.sh NAME -DCONV_DIAG=n): 1 no epilogue, 2 no MFMAs, 3 window staged for slab 0 only, 4 weight slab loaded once
+#define CONV_DIAG 0  // diagnostic builds of conv1d_kernel (tools/build_variant.sh NAME -DCONV_DIAG=n): 1 no epilogue, 2 no MFMAs, 3 window staged for slab 0 only, 4 weight slab loaded once, 5 16-bit output wrapped into 1 024 rows, 6 per-workgroup clock stamps (tts_conv_diag_trace)
 #endif
 
 namespace tts {
@@ -91,6 +91,24 @@ struct Elem<false, F16> {
   using T = float;
   static __device__ __forceinline__ float cvt(float v) { return v; }
 };
+
+#if CONV_DIAG == 6
+__device__ unsigned long long g_conv_trace[4096][4];
+}  // namespace tts
+extern "C" int tts_conv_diag_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(tts::g_conv_trace), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+namespace tts {
+#endif
+
+// compile-time loop: f(integral_constant<int, K>) for K = K0 .. N-1
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (K < N) {
+    f(std::integral_constant<int, K>{});
+    static_for<K + 1, N>(f);
+  }
+}
 
 // One output element of the fused epilogue, up to the store: a / g are the raw accumulators (g: the gate half in the dual modes),
 // ba / bg the biases, sv the per-utterance vector, pa / pg the pre-add, ax the coupling input, rv the residual.  Shared by every
@@ -162,10 +180,92 @@ __device__ __forceinline__ bool epilogue_vec_ok(const TtsConvDesc& d) {
 // -DCONV_DIAG=1.)  A row's pieces are written by one wavefront within a few hundred cycles: L2 merges them into whole lines.
 template <int TM, int TN, int NH, bool DUAL>
 __device__ __forceinline__ void conv_epilogue_t(const TtsConvDesc& d, const TtsTile& tile, int n0, int wm, int wn, int lrow, int lk,
-                                                const f32x16 (&acc)[NH][TM][TN]) {
+                                                const f32x16 (&acc)[NH][TM][TN], const float* eb = nullptr, int eb_n = 0) {
   const bool io_f16 = d.io_flags & TTS_IO_F16;  // format of the 16-bit tensors of this call (else bf16)
   const bool vec = epilogue_vec_ok(d);
   const bool y16 = d.io_flags & TTS_IO_Y_BF16, r16 = d.io_flags & TTS_IO_RES_BF16;
+  if constexpr (!DUAL) {
+    if (vec && !d.preadd && eb) {
+      // The common case (plain convs: bias, per-utterance vector, residual, accumulate).  What was measured on the 128 x 128 tile at
+      // 256 -> 256 channels (clock stamps, -DCONV_DIAG=6): main loop 41.7 k cycles, epilogue 21.9 k - not the stores (they drain in
+      // 0.4 k), but sixteen dependent global-load round trips per lane (bias, vector, residual of each 4-channel group, each ~1.4 k
+      // cycles, and behind earlier stores: loads and stores share the in-order vmcnt counter, so a load issued after a store is usable
+      // only once that store is acknowledged).  Hence: bias and per-utterance vector come from LDS (`eb`, staged at kernel start), and
+      // all residual / accumulate reads of a 32-row block are issued together, in front of its stores: one round trip per block.
+      auto col_of = [&](int j, int rq) { return n0 + (wn * TN + j) * 32 + 8 * rq + 4 * lk; };
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = tile.row0 + (wm * TM + i) * 32 + lrow;
+        const int rowc = row < tile.seq_end ? row : tile.seq_end - 1;  // (clamped: unconditional loads; rows behind the utterance are never stored)
+        constexpr int NG = TN * 4, CH = 8;  // 4-channel groups of the block, and how many of them travel together (registers: 8 per group)
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += CH) {
+        uint4 rv[CH], yv[CH];
+#pragma unroll
+          for (int g = 0; g < CH; ++g) {
+            if (g0 + g >= NG) continue;
+            const int j = (g0 + g) >> 2, rq = (g0 + g) & 3;
+            int n = col_of(j, rq);
+            n = n < d.cout ? n : d.cout - 4;
+            rv[g] = make_uint4(0, 0, 0, 0);
+            yv[g] = make_uint4(0, 0, 0, 0);
+            if (d.res) {
+              if (r16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(d.res) + (size_t)rowc * d.ld_res + n);
+                rv[g].x = u.x; rv[g].y = u.y;
+              } else {
+                rv[g] = *reinterpret_cast<const uint4*>(d.res + (size_t)rowc * d.ld_res + n);
+              }
+            }
+            if (d.accumulate) {
+              if (y16) {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(d.y) + (size_t)rowc * d.ldy + n);
+                yv[g].x = u.x; yv[g].y = u.y;
+              } else {
+                yv[g] = *reinterpret_cast<const uint4*>(d.y + (size_t)rowc * d.ldy + n);
+              }
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);  // (all loads of the chunk in front of its first store)
+        if (row < tile.seq_end) {
+#pragma unroll
+          for (int g = 0; g < CH; ++g) {
+            if (g0 + g >= NG) continue;
+            const int j = (g0 + g) >> 2, rq = (g0 + g) & 3;
+            const int n = col_of(j, rq);
+            if (n >= d.cout) continue;
+            const float4 ba = *reinterpret_cast<const float4*>(eb + (n - n0));
+            const float4 sv = *reinterpret_cast<const float4*>(eb + eb_n + (n - n0));
+            const uint4 ru = rv[g], yu = yv[g];
+            float4 r4, y4;
+            if (r16) r4 = make_float4(load16(ru.x & 0xFFFF, io_f16), load16(ru.x >> 16, io_f16), load16(ru.y & 0xFFFF, io_f16), load16(ru.y >> 16, io_f16));
+            else r4 = make_float4(__builtin_bit_cast(float, ru.x), __builtin_bit_cast(float, ru.y), __builtin_bit_cast(float, ru.z), __builtin_bit_cast(float, ru.w));
+            if (y16) y4 = make_float4(load16(yu.x & 0xFFFF, io_f16), load16(yu.x >> 16, io_f16), load16(yu.y & 0xFFFF, io_f16), load16(yu.y >> 16, io_f16));
+            else y4 = make_float4(__builtin_bit_cast(float, yu.x), __builtin_bit_cast(float, yu.y), __builtin_bit_cast(float, yu.z), __builtin_bit_cast(float, yu.w));
+            float v0 = epilogue_value<false>(d, acc[0][i][j][4 * rq + 0], 0.f, ba.x, 0.f, sv.x, 0.f, 0.f, 0.f, r4.x);
+            float v1 = epilogue_value<false>(d, acc[0][i][j][4 * rq + 1], 0.f, ba.y, 0.f, sv.y, 0.f, 0.f, 0.f, r4.y);
+            float v2 = epilogue_value<false>(d, acc[0][i][j][4 * rq + 2], 0.f, ba.z, 0.f, sv.z, 0.f, 0.f, 0.f, r4.z);
+            float v3 = epilogue_value<false>(d, acc[0][i][j][4 * rq + 3], 0.f, ba.w, 0.f, sv.w, 0.f, 0.f, 0.f, r4.w);
+            if (d.accumulate) { v0 += y4.x; v1 += y4.y; v2 += y4.z; v3 += y4.w; }
+            if (y16) {
+#if CONV_DIAG == 5  // diagnostic: the output lands in 1 024 rows over and over (stays in L2: no HBM write stream)
+              uint2* yp = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(d.y) + (size_t)(row & 1023) * d.ldy + n);
+#else
+              uint2* yp = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n);
+#endif
+              *yp = make_uint2((unsigned int)store16(v0, io_f16) | ((unsigned int)store16(v1, io_f16) << 16),
+                               (unsigned int)store16(v2, io_f16) | ((unsigned int)store16(v3, io_f16) << 16));
+            } else {
+              *reinterpret_cast<float4*>(d.y + (size_t)row * d.ldy + n) = make_float4(v0, v1, v2, v3);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = tile.row0 + (wm * TM + i) * 32 + lrow;
@@ -281,8 +381,15 @@ __device__ __forceinline__ void conv_epilogue16(const TtsConvDesc& d, const TtsT
 // (two accumulator sets: the hi.hi sums and the cross sums, combined once before the epilogue) - ~22 significant bits per product
 // at 16/3 of the fp32 matrix rate.  The window and the weight slabs carry two fp16 planes each (weights pre-split by the host:
 // w16 = [hi | lo'] planes of [tap][cin_pad/8][wn][8]); everything else - tiling, staging, epilogue - is the 16-bit path's.
+// Wavefronts per SIMD the register allocator has to leave room for: three workgroups per CU for the 128 x 128 tile (its pipelined
+// epilogue otherwise takes 107 + 64 registers, four over the line); no constraint elsewhere.
+constexpr int conv_min_waves(int tm, int tn, bool dual, bool bf16, bool snake, bool x3) {
+  return (((tm == 2 && tn == 2) || (tm == 1 && tn == 3)) && !dual && !snake && !x3) ? 3 : 1;  // (128 x 128 and 128 x 96 tiles, both element types)
+}
+
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool DUAL, bool BF16, bool SNAKE, bool F16, bool X3 = false>
-__global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_min_waves(TM, TN, DUAL, BF16, SNAKE, X3))))
+void conv1d_kernel(const TtsConvDesc d) {
   static_assert(BF16 || !F16, "F16 selects the element format of the 16-bit MFMA path");
   static_assert(!X3 || (BF16 && F16 && !SNAKE), "the split fp32 product runs on the fp16 path");
   using C = ConvCfg<TM, TN, WAVES_M, WAVES_N, DUAL>;
@@ -298,6 +405,9 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   constexpr int UPT = UNITS / 256;                  // units per thread
   static_assert(UNITS % 256 == 0, "slab must split evenly over the workgroup");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#if CONV_DIAG == 6
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
   const TtsTile tile = d.tiles[blockIdx.x];
   const int n0 = blockIdx.y * BN;  // first output column (within a half in dual mode)
@@ -314,6 +424,8 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
   ET* xs0 = reinterpret_cast<ET*>(lds_raw);                                 // [1 or 2][win_rows][XP]  (X3: [2 planes][win_rows][XP])
   ET* ws = xs0 + ((WIN2 || X3) ? 2 : 1) * xs_elems;                         // [2][NH][NP][BK*BN]
   constexpr int WBUF = NH * NP * BK * BN;
+  // plain convs: bias and per-utterance vector of the workgroup's BN columns, for the epilogue (visible behind the main loop's barriers)
+  float* eb = DUAL ? nullptr : reinterpret_cast<float*>(ws + (size_t)2 * WBUF);  // [2][BN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -337,6 +449,13 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
           if constexpr (X3) accx[h][i][j][r] = 0.0f;
         }
 
+  if constexpr (!DUAL) {
+    if (threadIdx.x < BN) {
+      const int n = n0 + threadIdx.x;
+      eb[threadIdx.x] = (d.bias && n < d.cout) ? d.bias[n] : 0.0f;
+      eb[BN + threadIdx.x] = (d.seqvec && n < d.cout) ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n] : 0.0f;
+    }
+  }
   const int row_first = tile.row0 - d.pad_left;  // packed row of window row 0
   const bool x_bf16 = d.io_flags & TTS_IO_X_BF16;  // x is a 16-bit tensor ...
   const bool x_f16 = BF16 ? F16 : (d.io_flags & TTS_IO_F16) != 0;  // ... of this format (a 16-bit kernel only meets its own)
@@ -704,7 +823,17 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[h][i][j][r] = fmaf(accx[h][i][j][r], 1.0f / 2048.0f, acc[h][i][j][r]);
   }
-#if CONV_DIAG == 1
+#if CONV_DIAG == 6  // diagnostic: per-workgroup clocks (start, main loop done, epilogue issued, epilogue drained) of wavefront 0
+  const unsigned long long diag_t1 = __builtin_amdgcn_s_memtime();
+  conv_epilogue_t<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc, eb, BN);
+  const unsigned long long diag_t2 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long diag_t3 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    const unsigned int slot = (blockIdx.y * gridDim.x + blockIdx.x) & 4095;
+    g_conv_trace[slot][0] = diag_t0; g_conv_trace[slot][1] = diag_t1; g_conv_trace[slot][2] = diag_t2; g_conv_trace[slot][3] = diag_t3;
+  }
+#elif CONV_DIAG == 1
   {  // diagnostic build: no epilogue (one never-taken store keeps the accumulators alive)
     float t = 0.f;
 #pragma unroll
@@ -716,7 +845,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const TtsConvDesc d) {
     if (t == 1.2345e-30f) d.y[0] = t;
   }
 #else
-  conv_epilogue_t<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
+  conv_epilogue_t<TM, TN, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc, eb, BN);
 #endif
 }
 
@@ -1096,7 +1225,8 @@ static int launch_one(const TtsConvDesc& d, hipStream_t st) {
   const int n_tiles_n = ((DUAL ? d.half_pad : d.wn) + C::BN - 1) / C::BN;
   dim3 grid(d.n_tiles, n_tiles_n), block(256);
   const size_t xs_elems = ((size_t)win_rows * XP + 7) & ~(size_t)7;
-  const size_t lds = (((C::BM == 64 && !SNAKE) || X3 ? 2 : 1) * xs_elems + (size_t)2 * NH * (X3 ? 2 : 1) * BK * C::BN) * ESZ;
+  const size_t lds = (((C::BM == 64 && !SNAKE) || X3 ? 2 : 1) * xs_elems + (size_t)2 * NH * (X3 ? 2 : 1) * BK * C::BN) * ESZ +
+                     (DUAL ? 0 : 2 * C::BN * sizeof(float));  // (+ the epilogue's bias / per-utterance vector)
   TTS_CHECK_ARG(lds <= 160 * 1024, "conv1d: LDS %zu B exceeds 160 KiB (taps %d dil %d)", lds, d.taps, d.dil);
   auto k = conv1d_kernel<TM, TN, WAVES_M, WAVES_N, DUAL, BF16, SNAKE, F16, X3>;
   static unsigned long long lds_raised = 0;  // devices on which this instantiation's limit is already raised

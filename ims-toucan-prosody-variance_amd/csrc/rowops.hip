@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // Layers/ConditionalLayerNorm.py:52-67: y = scale[u] * (x - mean) / var + shift[u]   (variance, not std; no eps)
+constexpr int CLN_ROWS = 8;  // rows per workgroup (two per wavefront)
 __global__ __launch_bounds__(256) void cln_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy,
                                                   const float* __restrict__ scale, const float* __restrict__ shift, int c,
                                                   const TtsTile* __restrict__ tiles, int tile_rows) {
@@ -49,7 +50,10 @@ __global__ __launch_bounds__(256) void cln_kernel(const float* __restrict__ x, i
   const int lane = threadIdx.x & 63;
   const float* sc = scale + (size_t)t.seq_id * c;
   const float* sh = shift + (size_t)t.seq_id * c;
-  for (int rr = threadIdx.x >> 6; rr < tile_rows; rr += 4) {
+  // blockIdx.y: a run of CLN_ROWS rows of the tile (one workgroup per 128-row tile left a wavefront 32 dependent row round trips:
+  // 25 us for the 128 rows of a batch-1 pass, 48 us at batch 32)
+  const int r_end = min(tile_rows, ((int)blockIdx.y + 1) * CLN_ROWS);
+  for (int rr = blockIdx.y * CLN_ROWS + (threadIdx.x >> 6); rr < r_end; rr += 4) {
     const int row = t.row0 + rr;
     if (row >= t.seq_end) break;
     const float* xr = x + (size_t)row * ldx;
@@ -95,11 +99,12 @@ __global__ __launch_bounds__(64) void l2norm_kernel(const float* __restrict__ x,
 // GroupNorm over (c/groups channels) x (all frames of ONE utterance) + affine + optional tanh + optional residual.
 // Layers/PostNet.py:44-56 (GroupNorm(32,256) x4 with Tanh, GroupNorm(20,80) last), eps 1e-5.
 // The statistics are a time-axis reduction, so they MUST be per utterance (padding may never leak in).
-// Two launches over a (64-frame chunk, utterance) grid, thread = channel (c <= 256, whole rows = contiguous segments):
+// Two launches over a (16-frame chunk, utterance) grid, thread = channel (c <= 256, whole rows = contiguous segments; 64-frame
+// chunks until round 3: 10 workgroups for the 640 frames of a batch-1 pass, 16 + 21 us per norm):
 //   1. partial (sum, sum of squares) per (utterance, chunk, group) into a workspace - no atomics, so the result is
 //      bit-reproducible from run to run and across ranks;
-//   2. every workgroup adds the partials of its utterance in chunk order (fp64), then normalises its own 64 frames.
-constexpr int GN_CHUNK = 64;
+//   2. every workgroup adds the partials of its utterance in chunk order (fp64), then normalises its own 16 frames.
+constexpr int GN_CHUNK = 16;
 
 __global__ __launch_bounds__(256) void groupnorm_partial_kernel(const float* __restrict__ x, int ldx, int c, int groups,
                                                                 const int* __restrict__ seq_begin, const int* __restrict__ seq_end,
@@ -243,7 +248,7 @@ int cond_layernorm(const float* x, int ldx, float* y, int ldy, const float* sc, 
                    int n_tiles, int tile_rows, hipStream_t st) {
   TTS_CHECK_ARG(c > 0 && c <= 64 * MAX_PER_LANE, "cond_layernorm: c=%d unsupported", c);
   if (n_tiles == 0) return TTS_OK;
-  hipLaunchKernelGGL(cln_kernel, dim3(n_tiles), dim3(256), 0, st, x, ldx, y, ldy, sc, sh, c, tiles, tile_rows);
+  hipLaunchKernelGGL(cln_kernel, dim3(n_tiles, (tile_rows + CLN_ROWS - 1) / CLN_ROWS), dim3(256), 0, st, x, ldx, y, ldy, sc, sh, c, tiles, tile_rows);
   return launch_status("cond_layernorm");
 }
 

@@ -420,7 +420,7 @@ class Emulator:
         return 0
 
     def tts_groupnorm_workspace_floats(self, n_seq, max_len, groups):
-        return n_seq * ((max_len + 63) // 64) * groups * 2
+        return n_seq * ((max_len + 15) // 16) * groups * 2
 
     def tts_groupnorm(self, x, ldx, y, ldy, gamma, beta, c, groups, eps, apply_tanh, res, ld_res, seq_begin, seq_end, n_seq, max_len,
                       workspace, stream):
