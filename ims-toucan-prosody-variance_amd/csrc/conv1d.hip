@@ -329,45 +329,57 @@ __device__ __forceinline__ void conv_epilogue_t(const TtsConvDesc& d, const TtsT
   }
 }
 
-// Fused epilogue shared by the conv kernels; C/D layout of a 32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-// Wave (wm, wn) of the workgroup owns accumulator tiles [i][j] at rows tile.row0 + (wm*TM + i)*32, columns n0 + (wn*TN + j)*32.
-template <int TM, int TN, int NH, bool DUAL>
-__device__ __forceinline__ void conv_epilogue(const TtsConvDesc& d, const TtsTile& tile, int n0, int wm, int wn, int lrow, int lk,
-                                              const f32x16 (&acc)[NH][TM][TN]) {
-  const bool io_f16 = d.io_flags & TTS_IO_F16;  // format of the 16-bit tensors of this call (else bf16)
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 32 + j * 32 + lrow;
-      if (n >= d.cout) continue;
-      const float ba = d.bias ? d.bias[n] : 0.0f;
-      const float bg = (DUAL && d.bias) ? d.bias[d.cout + n] : 0.0f;
-      const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = tile.row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row >= tile.seq_end) continue;
-        epilogue_element<DUAL>(d, row, n, acc[0][i][j][r], acc[NH - 1][i][j][r], ba, bg, sv, io_f16);
-      }
-    }
-  }
-}
-
-// The same for one 16x16 accumulator (v_mfma_f32_16x16x4_f32): col = lane&15, row = reg + 4*(lane>>4), at rows row_base.., columns n0..
+// Epilogue of a TRANSPOSED 16x16 accumulator (v_mfma_f32_16x16x4_f32 with the weights as the A operand): row = lane&15, columns
+// reg + 4*(lane>>4) - four consecutive output channels of one row per lane: every operand is ONE vector load, all of them issued
+// before the single vector store (with the output channel on the lane the four elements of a lane were four load - wait - store
+// round trips, each load queued behind the previous element's store: ~6 us of a 7-11 us batch-1 launch).
 template <int NH, bool DUAL>
-__device__ __forceinline__ void conv_epilogue16(const TtsConvDesc& d, const TtsTile& tile, int n0, int row_base, int lane, const f32x4 (&acc)[NH]) {
+__device__ __forceinline__ void conv_epilogue16_t(const TtsConvDesc& d, const TtsTile& tile, int n0, int row_base, int lane, const f32x4 (&acc)[NH]) {
   const bool io_f16 = d.io_flags & TTS_IO_F16;
-  const int n = n0 + (lane & 15);
-  if (n >= d.cout) return;
-  const float ba = d.bias ? d.bias[n] : 0.0f;
-  const float bg = (DUAL && d.bias) ? d.bias[d.cout + n] : 0.0f;
-  const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = row_base + r + 4 * (lane >> 4);
-    if (row >= tile.seq_end) continue;
-    epilogue_element<DUAL>(d, row, n, acc[0][r], acc[NH - 1][r], ba, bg, sv, io_f16);
+  const int row = row_base + (lane & 15), n = n0 + 4 * (lane >> 4);
+  if (row >= tile.seq_end || n >= d.cout) return;
+  if (!epilogue_vec_ok(d)) {
+    for (int q = 0; q < 4 && n + q < d.cout; ++q) {
+      const float ba = d.bias ? d.bias[n + q] : 0.0f;
+      const float bg = (DUAL && d.bias) ? d.bias[d.cout + n + q] : 0.0f;
+      const float sv = d.seqvec ? d.seqvec[(size_t)tile.seq_id * d.ld_seqvec + n + q] : 0.0f;
+      epilogue_element<DUAL>(d, row, n + q, acc[0][q], acc[NH - 1][q], ba, bg, sv, io_f16);
+    }
+    return;
+  }
+  const bool y16 = d.io_flags & TTS_IO_Y_BF16, r16 = d.io_flags & TTS_IO_RES_BF16;
+  auto ld4 = [](const float* p) { return *reinterpret_cast<const float4*>(p); };
+  auto ld16 = [&](const float* base, size_t off) {  // four 16-bit elements -> fp32
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    return make_float4(load16(u.x & 0xFFFF, io_f16), load16(u.x >> 16, io_f16), load16(u.y & 0xFFFF, io_f16), load16(u.y >> 16, io_f16));
+  };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ba = z4, bg = z4, sv = z4, pa = z4, pg = z4, ax = z4, rv = z4, yv = z4;
+  if (d.bias) ba = ld4(d.bias + n);
+  if (DUAL && d.bias) bg = ld4(d.bias + d.cout + n);
+  if (d.seqvec) sv = ld4(d.seqvec + (size_t)tile.seq_id * d.ld_seqvec + n);
+  if (d.preadd) pa = ld4(d.preadd + (size_t)row * d.ld_preadd + n);
+  if (DUAL && d.preadd) pg = ld4(d.preadd + (size_t)row * d.ld_preadd + d.cout + n);
+  if (DUAL && d.mode == TTS_MODE_COUPLING) ax = ld4(d.aux + (size_t)row * d.ld_aux + n);
+  if (d.res) {
+    if (r16) rv = ld16(d.res, (size_t)row * d.ld_res + n);
+    else rv = ld4(d.res + (size_t)row * d.ld_res + n);
+  }
+  if (d.accumulate) {
+    if (y16) yv = ld16(d.y, (size_t)row * d.ldy + n);
+    else yv = ld4(d.y + (size_t)row * d.ldy + n);
+  }
+  float v0 = epilogue_value<DUAL>(d, acc[0][0], acc[NH - 1][0], ba.x, bg.x, sv.x, pa.x, pg.x, ax.x, rv.x);
+  float v1 = epilogue_value<DUAL>(d, acc[0][1], acc[NH - 1][1], ba.y, bg.y, sv.y, pa.y, pg.y, ax.y, rv.y);
+  float v2 = epilogue_value<DUAL>(d, acc[0][2], acc[NH - 1][2], ba.z, bg.z, sv.z, pa.z, pg.z, ax.z, rv.z);
+  float v3 = epilogue_value<DUAL>(d, acc[0][3], acc[NH - 1][3], ba.w, bg.w, sv.w, pa.w, pg.w, ax.w, rv.w);
+  if (d.accumulate) { v0 += yv.x; v1 += yv.y; v2 += yv.z; v3 += yv.w; }
+  if (y16) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(d.y) + (size_t)row * d.ldy + n) =
+        make_uint2((unsigned int)store16(v0, io_f16) | ((unsigned int)store16(v1, io_f16) << 16),
+                   (unsigned int)store16(v2, io_f16) | ((unsigned int)store16(v3, io_f16) << 16));
+  } else {
+    *reinterpret_cast<float4*>(d.y + (size_t)row * d.ldy + n) = make_float4(v0, v1, v2, v3);
   }
 }
 
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
         for (int h = 0; h < NH; ++h) bf[h] = b[h][u];  // copies: the slot is re-requested below while the MFMA may still read
 #pragma unroll
         for (int h = 0; h < NH; ++h)
-          acc[h][0][0] = mfma16<F16>(__builtin_bit_cast(bf16x8, ap), __builtin_bit_cast(bf16x8, bf[h]), acc[h][0][0]);
+          acc[h][0][0] = mfma16<F16>(__builtin_bit_cast(bf16x8, bf[h]), __builtin_bit_cast(bf16x8, ap), acc[h][0][0]);  // (transposed, as in conv1d_kernel)
         int nxt = base + u + DEPTH;
         nxt = nxt < n_steps ? nxt : n_steps - 1;  // the tail re-requests the last step (unused): no branch in the stream
         request(u, nxt);
@@ -992,7 +1004,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int h = 0; h < NH; ++h) acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[h][j], acc[h][0][0], 0, 0, 0);
+          for (int h = 0; h < NH; ++h) acc[h][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[h][j], av[j], acc[h][0][0], 0, 0, 0);
         int nxt = base + u + DEPTH;
         nxt = nxt < n_groups ? nxt : n_groups - 1;
         request(u, nxt);
@@ -1012,7 +1024,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const TtsConvDesc d) {
 #undef TTS_GLOAD32
 #undef TTS_WAIT_VM
 #undef TTS_PIN
-  conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
+  conv_epilogue_t<1, 1, NH, DUAL>(d, tile, n0, wm, wn, lrow, lk, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1139,8 +1151,9 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
         for (int q = 0; q < NA; ++q)
 #pragma unroll
           for (int h = 0; h < NH; ++h) {
-            if constexpr (T16) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][j], bv[h][4 * q + j], acc[h], 0, 0, 0);
-            else acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][j], bv[h][4 * q + j], acc[h], 0, 0, 0);
+            // (transposed: the weights are the A operand, so a lane ends up with consecutive channels of ONE row - vector epilogue)
+            if constexpr (T16) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[h][4 * q + j], av[q][j], acc[h], 0, 0, 0);
+            else acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[h][4 * q + j], av[q][j], acc[h], 0, 0, 0);
           }
       request(u);
     }
@@ -1172,12 +1185,12 @@ __global__ __launch_bounds__(256) void conv_splitk_f32_kernel(const TtsConvDesc 
 #pragma unroll
     for (int r = 0; r < AR; ++r) acc[h][r] = ((acc[h][r] + part[0][h][r][lane]) + part[1][h][r][lane]) + part[2][h][r][lane];
   if constexpr (T16) {
-    conv_epilogue16<NH, DUAL>(d, tile, n0, tile.row0 + sub * 16, lane, acc);
+    conv_epilogue16_t<NH, DUAL>(d, tile, n0, tile.row0 + sub * 16, lane, acc);
   } else {
     f32x16 acc32[NH][1][1];
 #pragma unroll
     for (int h = 0; h < NH; ++h) acc32[h][0][0] = acc[h];
-    conv_epilogue<1, 1, NH, DUAL>(d, tile, n0, sub, 0, lrow, kq, acc32);
+    conv_epilogue_t<1, 1, NH, DUAL>(d, tile, n0, sub, 0, lrow, kq, acc32);
   }
 }
 

@@ -27,13 +27,14 @@ def main():
     for name, M, cin, cout, k, mode in shapes:
         rs = np.random.RandomState(0)
         cw = packing.pack_conv((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32), np.zeros(cout, np.float32), dev, mode=mode, bf16=True)
+        cw3 = packing.pack_conv((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32), np.zeros(cout, np.float32), dev, mode=mode, bf16="x3")
         rag = Ragged([M], dev)
         x = torch.randn(rag.total_rows, cin, device=dev)
         y = torch.empty(rag.total_rows, cout // 2 if mode != capi.MODE_LINEAR else cout, device=dev)
-        for comp, cname in ((capi.COMPUTE_F32, "f32"), (capi.COMPUTE_BF16, "bf16")):
+        for comp, cname in ((capi.COMPUTE_F32, "f32"), (capi.COMPUTE_BF16, "bf16"), (capi.COMPUTE_F32X3, "f32x3")):
             for split in ((False, True) if comp == capi.COMPUTE_F32 else (False,)):
                 ops.split_k = int(split)  # fp32: also the split-K form the acoustic model opts into (TTS_IO_SPLIT_K)
-                run = lambda: ops.conv(cw, x, y, rag, compute=comp)
+                run = lambda: ops.conv(cw3 if comp == capi.COMPUTE_F32X3 else cw, x, y, rag, compute=comp)
                 for _ in range(3):
                     run()
                 torch.cuda.synchronize()
