@@ -118,6 +118,13 @@ struct SnakeFir {
   // interior test of the window starting at image row w (inputs w .. w + 21, outputs qo = w + 3 .. w + 18)
   __device__ __forceinline__ bool up_interior(int w) const { return frame0 + w >= 0 && frame0 + w + 21 <= T - 1; }
   __device__ __forceinline__ bool down_interior(int fo) const { return fo >= 3 && fo + 18 <= T - 1; }
+  // ... and of a window / output tile that lies outside the utterance altogether: every row of its operand is zero (gen_up / gen_down
+  // would return exactly that, after ~500 vector instructions each).  The tiles in front of an utterance's first frame and behind its
+  // last one - most of the last 224-row tile of an utterance - are of this kind: rebuilding their constants step by step made that
+  // one workgroup 3.5x slower than the others (107 k instead of 7.4 k cycles per sweep; at batch 1 the launch waited for it:
+  // 147 us instead of ~45 us at C = 128).  Only the one or two steps that straddle an edge still build constants.
+  __device__ __forceinline__ bool up_outside(int w) const { return frame0 + w + 18 < 0 || frame0 + w + 3 > T - 1; }
+  __device__ __forceinline__ bool down_outside(int fo) const { return fo + 15 < 0 || fo > T - 1; }
 
   // x window -> 32 2x-rate samples of s as a K-step fragment of the decimator (INNER: no tap folds onto an utterance edge)
   template <bool INNER>
@@ -125,8 +132,13 @@ struct SnakeFir {
     bf16x8 a0 = ua0, a1 = ua1;
     if constexpr (!INNER) {
       if (!up_interior(w)) {  // wave-uniform
-        a0 = gen_up(f, 0, frame0 + w, T, lane);
-        a1 = gen_up(f, 1, frame0 + w, T, lane);
+        if (up_outside(w)) {
+          a0 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          a1 = a0;
+        } else {
+          a0 = gen_up(f, 0, frame0 + w, T, lane);
+          a1 = gen_up(f, 1, frame0 + w, T, lane);
+        }
       }
     }
 #ifdef SNAKE_SIN2  // (A/B switch: the five-operation form u + inv_b sin^2(u e^alpha))
@@ -193,8 +205,13 @@ struct SnakeFir {
       if constexpr (!INNER) {
         const int fo = frame0 + row_begin + 6 + 16 * i;
         if (!down_interior(fo)) {  // (rows of D for frames outside [0, T) are zero: those outputs are the convs' zero padding)
-          d0 = gen_down(f, 0, fo, T, lane);
-          d1 = gen_down(f, 1, fo, T, lane);
+          if (down_outside(fo)) {
+            d0 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            d1 = d0;
+          } else {
+            d0 = gen_down(f, 0, fo, T, lane);
+            d1 = gen_down(f, 1, fo, T, lane);
+          }
         }
       }
       f32x4v y = {0.f, 0.f, 0.f, 0.f};
