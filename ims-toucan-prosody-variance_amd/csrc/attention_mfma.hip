@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void relpos_attention_mfma_kernel(const float*
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int AH_PK = AM_DK + 8;   // fp16 row pitch of K / table rows (112 B: 16-byte aligned, odd number of 16-byte slots)
 constexpr int AH_PV = AM_KT + 8;   // fp16 row pitch of V^T (80 B)
+constexpr int AH_SUB = 2;          // 32-key tiles staged per step (one pair of barriers and one exposed round of loads per 64 keys; the
+                                   // soft-max still advances 32 keys at a time, so the arithmetic is that of single-tile steps)
+constexpr int AH_PROWS = AM_PW + 1 + 32 * (AH_SUB - 1);  // table rows per step: 128 queries x 64 keys -> 191 relative positions
 
 __global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                                    const float* __restrict__ ptab, int pmax,
@@ -246,10 +249,10 @@ __global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* 
                                                                    float* __restrict__ ctx, int ld_ctx, int heads,
                                                                    const TtsTile* __restrict__ tiles) {
   extern __shared__ __attribute__((aligned(16))) float am_lds[];
-  unsigned short* Ks = reinterpret_cast<unsigned short*>(am_lds);   // [KT][PK]
-  unsigned short* Vt = Ks + AM_KT * AH_PK;                          // [DK][PV]: V^T, keys in operand order
-  unsigned short* Ps = Vt + AM_DK * AH_PV;                          // [PW + 1][PK]
-  float* Gs = reinterpret_cast<float*>(Ps + (AM_PW + 1) * AH_PK);   // [4][64 * GP] per-wave scratch
+  unsigned short* Ks = reinterpret_cast<unsigned short*>(am_lds);   // [SUB * KT][PK]
+  unsigned short* Vt = Ks + AH_SUB * AM_KT * AH_PK;                 // [SUB][DK][PV]: V^T, keys in operand order
+  unsigned short* Ps = Vt + AH_SUB * AM_DK * AH_PV;                 // [PROWS][PK]
+  float* Gs = reinterpret_cast<float*>(Ps + AH_PROWS * AH_PK);      // [4][64 * GP] per-wave scratch
 
   const TtsTile t = tiles[blockIdx.x];
   const int h = blockIdx.y;
@@ -287,25 +290,28 @@ __global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* 
   float m_run = -INFINITY, l_run = 0.f;
   const float scale = 1.0f / sqrtf((float)AM_DK);
 
-  for (int j0 = 0; j0 < n; j0 += AM_KT) {
+  for (int j00 = 0; j00 < n; j00 += AH_SUB * AM_KT) {
     __syncthreads();
-    // ---- stage K (rows), V (transposed, keys in operand order) and the table window, fp16 ----
-    for (int e = tid; e < AM_KT * (AM_DK / 4); e += 256) {
-      const int jj = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
-      const int jr = j0 + jj < n ? j0 + jj : n - 1;
+    // ---- stage K (rows), V (transposed, keys in operand order) of AH_SUB key tiles and their table window, fp16 ----
+    for (int e = tid; e < AH_SUB * AM_KT * (AM_DK / 4); e += 256) {
+      const int jk = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
+      const int jr = j00 + jk < n ? j00 + jk : n - 1;
       const float* base = qkv + (size_t)(t.seq_begin + jr) * ld_qkv + h * AM_DK + c4;
       const float4 kv = *reinterpret_cast<const float4*>(base + hd);
       const float4 vv = *reinterpret_cast<const float4*>(base + 2 * hd);
-      *reinterpret_cast<uint2*>(Ks + jj * AH_PK + c4) = make_uint2(pack16<true>(kv.x, kv.y), pack16<true>(kv.z, kv.w));
-      // key jj of the tile -> slot of the 16-deep products: k step jj >> 4; inside it lane half ((jj >> 2) & 1), element (jj & 3) + 4 ((jj >> 3) & 1)
+      *reinterpret_cast<uint2*>(Ks + jk * AH_PK + c4) = make_uint2(pack16<true>(kv.x, kv.y), pack16<true>(kv.z, kv.w));
+      // key jj of its tile -> slot of the 16-deep products: k step jj >> 4; inside it lane half ((jj >> 2) & 1), element (jj & 3) + 4 ((jj >> 3) & 1)
+      const int jj = jk & (AM_KT - 1);
       const int slot = (jj & 16) + 8 * ((jj >> 2) & 1) + (jj & 3) + 4 * ((jj >> 3) & 1);
-      Vt[(c4 + 0) * AH_PV + slot] = f32_to_f16(vv.x);
-      Vt[(c4 + 1) * AH_PV + slot] = f32_to_f16(vv.y);
-      Vt[(c4 + 2) * AH_PV + slot] = f32_to_f16(vv.z);
-      Vt[(c4 + 3) * AH_PV + slot] = f32_to_f16(vv.w);
+      unsigned short* vt = Vt + (jk / AM_KT) * AM_DK * AH_PV;
+      vt[(c4 + 0) * AH_PV + slot] = f32_to_f16(vv.x);
+      vt[(c4 + 1) * AH_PV + slot] = f32_to_f16(vv.y);
+      vt[(c4 + 2) * AH_PV + slot] = f32_to_f16(vv.z);
+      vt[(c4 + 3) * AH_PV + slot] = f32_to_f16(vv.w);
     }
-    const int p0 = qbase - j0 - (AM_KT - 1);
-    for (int e = tid; e < (AM_PW + 1) * (AM_DK / 4); e += 256) {
+    // window row w <-> relative position p0 + w; the LAST staged tile needs the lowest positions: p0 = qbase - (j00 + 32 (SUB - 1)) - 31
+    const int p0 = qbase - j00 - (AH_SUB * AM_KT - 1);
+    for (int e = tid; e < AH_PROWS * (AM_DK / 4); e += 256) {
       const int w = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
       int pr = pmax - 1 + p0 + w;
       pr = pr < 0 ? 0 : (pr > 2 * pmax - 2 ? 2 * pmax - 2 : pr);  // only reached by masked keys / discarded queries
@@ -314,14 +320,20 @@ __global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* 
     }
     __syncthreads();
 
+    for (int sub = 0; sub < AH_SUB; ++sub) {
+    const int j0 = j00 + sub * AM_KT;
+    if (j0 >= n) break;  // (wave-uniform: a key tile wholly behind the utterance)
+    const unsigned short* Ksub = Ks + sub * AM_KT * AH_PK;
+    const unsigned short* Vsub = Vt + sub * AM_DK * AH_PV;
     // ---- S^T = K (Q+u)^T, G^T = Pwin (Q+v)^T (this wave's 64-row sub-window): 3 + 6 MFMAs ----
     f32x16 s, g0, g1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; g0[r] = 0.f; g1[r] = 0.f; }
-    const unsigned short* pw = Ps + (wave * 32) * AH_PK;
+    // (tile `sub` of the step: its positions start 32 (SUB - 1 - sub) rows into the staged window)
+    const unsigned short* pw = Ps + (32 * (AH_SUB - 1 - sub) + wave * 32) * AH_PK;
 #pragma unroll
     for (int ks = 0; ks < AM_DK / 16; ++ks) {
-      const bf16x8 ak = *reinterpret_cast<const bf16x8*>(Ks + li * AH_PK + 16 * ks + 8 * hi);
+      const bf16x8 ak = *reinterpret_cast<const bf16x8*>(Ksub + li * AH_PK + 16 * ks + 8 * hi);
       const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(pw + li * AH_PK + 16 * ks + 8 * hi);
       const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(pw + (32 + li) * AH_PK + 16 * ks + 8 * hi);
       s = mfma16<true>(ak, qu[ks], s);
@@ -366,10 +378,12 @@ __global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* 
     const u32x4 pb0 = {pack16<true>(s[0], s[1]), pack16<true>(s[2], s[3]), pack16<true>(s[4], s[5]), pack16<true>(s[6], s[7])};
     const u32x4 pb1 = {pack16<true>(s[8], s[9]), pack16<true>(s[10], s[11]), pack16<true>(s[12], s[13]), pack16<true>(s[14], s[15])};
     const int d1 = li < 16 ? 32 + li : 47;  // d = 32..47 valid; rows 48..63 of O^T are discarded
-    o0 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + li * AH_PV + 8 * hi), __builtin_bit_cast(bf16x8, pb0), o0);
-    o1 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + d1 * AH_PV + 8 * hi), __builtin_bit_cast(bf16x8, pb0), o1);
-    o0 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + li * AH_PV + 16 + 8 * hi), __builtin_bit_cast(bf16x8, pb1), o0);
-    o1 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vt + d1 * AH_PV + 16 + 8 * hi), __builtin_bit_cast(bf16x8, pb1), o1);
+    o0 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vsub + li * AH_PV + 8 * hi), __builtin_bit_cast(bf16x8, pb0), o0);
+    o1 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vsub + d1 * AH_PV + 8 * hi), __builtin_bit_cast(bf16x8, pb0), o1);
+    o0 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vsub + li * AH_PV + 16 + 8 * hi), __builtin_bit_cast(bf16x8, pb1), o0);
+    o1 = mfma16<true>(*reinterpret_cast<const bf16x8*>(Vsub + d1 * AH_PV + 16 + 8 * hi), __builtin_bit_cast(bf16x8, pb1), o1);
+    // (the per-wave scratch `gs` is written again by the next tile: this wave's reads of it are done - same-wave DS order)
+    }
   }
 
   // ---- ctx[i][h*dk + d] = O^T[d][i] / l : transpose through the scratch so that every row is written contiguously ----
@@ -404,7 +418,9 @@ int relpos_attention_f16(const float* qkv, int ld_qkv, const float* ptab, int pm
                 "relpos_attention_f16: alignment");
   TTS_CHECK_ARG((ld_ctx & 3) == 0 && ((uintptr_t)ctx & 15) == 0, "relpos_attention_f16: ctx alignment");
   if (n_tiles == 0) return TTS_OK;
-  const size_t lds = (size_t)(AM_KT * AH_PK + AM_DK * AH_PV + (AM_PW + 1) * AH_PK) * 2 + (size_t)4 * 64 * AM_GP * sizeof(float);
+  const size_t lds = (size_t)(AH_SUB * AM_KT * AH_PK + AH_SUB * AM_DK * AH_PV + AH_PROWS * AH_PK) * 2 + (size_t)4 * 64 * AM_GP * sizeof(float);
+  static unsigned long long lds_raised = 0;
+  if (lds > 64 * 1024) (void)raise_lds_limit(reinterpret_cast<const void*>(relpos_attention_f16_kernel), lds_raised);
   hipLaunchKernelGGL(relpos_attention_f16_kernel, dim3(n_tiles, heads), dim3(256), lds, st, qkv, ld_qkv, ptab, pmax, bias_u, bias_v, ctx, ld_ctx,
                      heads, tiles);
   return launch_status("relpos_attention_f16");
