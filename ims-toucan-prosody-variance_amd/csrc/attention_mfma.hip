@@ -243,7 +243,7 @@ constexpr int AH_SUB = 2;          // 32-key tiles staged per step (one pair of 
                                    // soft-max still advances 32 keys at a time, so the arithmetic is that of single-tile steps)
 constexpr int AH_PROWS = AM_PW + 1 + 32 * (AH_SUB - 1);  // table rows per step: 128 queries x 64 keys -> 191 relative positions
 
-__global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* __restrict__ qkv, int ld_qkv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void relpos_attention_f16_kernel(const float* __restrict__ qkv, int ld_qkv,
                                                                    const float* __restrict__ ptab, int pmax,
                                                                    const float* __restrict__ bias_u, const float* __restrict__ bias_v,
                                                                    float* __restrict__ ctx, int ld_ctx, int heads,
@@ -290,35 +290,66 @@ __global__ __launch_bounds__(256) void relpos_attention_f16_kernel(const float* 
   float m_run = -INFINITY, l_run = 0.f;
   const float scale = 1.0f / sqrtf((float)AM_DK);
 
-  for (int j00 = 0; j00 < n; j00 += AH_SUB * AM_KT) {
-    __syncthreads();
-    // ---- stage K (rows), V (transposed, keys in operand order) of AH_SUB key tiles and their table window, fp16 ----
-    for (int e = tid; e < AH_SUB * AM_KT * (AM_DK / 4); e += 256) {
+  // The table window of step j00 + 64 is REQUESTED (global loads into registers) right behind the barrier that publishes step j00's
+  // operands, so it flies under the matrix work of step j00; it is converted and written to LDS at the top of the next iteration.
+  // (Loaded, converted and stored in one go, every step began with an exposed round of 15 loads per thread; K / V are 6 of them.)
+  constexpr int NKV = AH_SUB * AM_KT * (AM_DK / 4) / 256, NPT = AH_PROWS * (AM_DK / 4) / 256;  // items per thread: 3 and 9
+  static_assert(AH_SUB * AM_KT * (AM_DK / 4) % 256 == 0 && AH_PROWS * (AM_DK / 4) % 256 == 0, "staging items must tile the workgroup");
+  float4 rp[NPT];
+  auto request = [&](int j00) __attribute__((always_inline)) {
+    // window row w <-> relative position p0 + w; the LAST staged tile needs the lowest positions: p0 = qbase - (j00 + 32 (SUB - 1)) - 31
+    const int p0 = qbase - j00 - (AH_SUB * AM_KT - 1);
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+      const int e = tid + q * 256;
+      const int w = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
+      int pr = pmax - 1 + p0 + w;
+      pr = pr < 0 ? 0 : (pr > 2 * pmax - 2 ? 2 * pmax - 2 : pr);  // only reached by masked keys / discarded queries
+      rp[q] = *reinterpret_cast<const float4*>(ptab + (size_t)pr * hd + h * AM_DK + c4);
+    }
+  };
+  auto commit = [&](int j00) __attribute__((always_inline)) {
+    // ---- K (rows), V (transposed, keys in operand order) of AH_SUB key tiles (loaded here: with them prefetched too the kernel needs
+    // more than the 256 registers two workgroups per CU leave a wavefront) and the prefetched table window, fp16 ----
+    float4 rk[NKV], rv[NKV];
+#pragma unroll
+    for (int q = 0; q < NKV; ++q) {
+      const int e = tid + q * 256;
       const int jk = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
       const int jr = j00 + jk < n ? j00 + jk : n - 1;
       const float* base = qkv + (size_t)(t.seq_begin + jr) * ld_qkv + h * AM_DK + c4;
-      const float4 kv = *reinterpret_cast<const float4*>(base + hd);
-      const float4 vv = *reinterpret_cast<const float4*>(base + 2 * hd);
-      *reinterpret_cast<uint2*>(Ks + jk * AH_PK + c4) = make_uint2(pack16<true>(kv.x, kv.y), pack16<true>(kv.z, kv.w));
+      rk[q] = *reinterpret_cast<const float4*>(base + hd);
+      rv[q] = *reinterpret_cast<const float4*>(base + 2 * hd);
+    }
+#pragma unroll
+    for (int q = 0; q < NKV; ++q) {
+      const int e = tid + q * 256;
+      const int jk = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
+      *reinterpret_cast<uint2*>(Ks + jk * AH_PK + c4) = make_uint2(pack16<true>(rk[q].x, rk[q].y), pack16<true>(rk[q].z, rk[q].w));
       // key jj of its tile -> slot of the 16-deep products: k step jj >> 4; inside it lane half ((jj >> 2) & 1), element (jj & 3) + 4 ((jj >> 3) & 1)
       const int jj = jk & (AM_KT - 1);
       const int slot = (jj & 16) + 8 * ((jj >> 2) & 1) + (jj & 3) + 4 * ((jj >> 3) & 1);
       unsigned short* vt = Vt + (jk / AM_KT) * AM_DK * AH_PV;
-      vt[(c4 + 0) * AH_PV + slot] = f32_to_f16(vv.x);
-      vt[(c4 + 1) * AH_PV + slot] = f32_to_f16(vv.y);
-      vt[(c4 + 2) * AH_PV + slot] = f32_to_f16(vv.z);
-      vt[(c4 + 3) * AH_PV + slot] = f32_to_f16(vv.w);
+      vt[(c4 + 0) * AH_PV + slot] = f32_to_f16(rv[q].x);
+      vt[(c4 + 1) * AH_PV + slot] = f32_to_f16(rv[q].y);
+      vt[(c4 + 2) * AH_PV + slot] = f32_to_f16(rv[q].z);
+      vt[(c4 + 3) * AH_PV + slot] = f32_to_f16(rv[q].w);
     }
-    // window row w <-> relative position p0 + w; the LAST staged tile needs the lowest positions: p0 = qbase - (j00 + 32 (SUB - 1)) - 31
-    const int p0 = qbase - j00 - (AH_SUB * AM_KT - 1);
-    for (int e = tid; e < AH_PROWS * (AM_DK / 4); e += 256) {
+#pragma unroll
+    for (int q = 0; q < NPT; ++q) {
+      const int e = tid + q * 256;
       const int w = e / (AM_DK / 4), c4 = (e % (AM_DK / 4)) * 4;
-      int pr = pmax - 1 + p0 + w;
-      pr = pr < 0 ? 0 : (pr > 2 * pmax - 2 ? 2 * pmax - 2 : pr);  // only reached by masked keys / discarded queries
-      const float4 pv = *reinterpret_cast<const float4*>(ptab + (size_t)pr * hd + h * AM_DK + c4);
-      *reinterpret_cast<uint2*>(Ps + w * AH_PK + c4) = make_uint2(pack16<true>(pv.x, pv.y), pack16<true>(pv.z, pv.w));
+      *reinterpret_cast<uint2*>(Ps + w * AH_PK + c4) = make_uint2(pack16<true>(rp[q].x, rp[q].y), pack16<true>(rp[q].z, rp[q].w));
     }
+  };
+  request(0);
+  for (int j00 = 0; j00 < n; j00 += AH_SUB * AM_KT) {
+    __syncthreads();  // (every wavefront is done with the previous step's LDS operands)
+    commit(j00);
     __syncthreads();
+    // (unconditional: past the last step the clamped addresses re-read the last rows - a value defined on one side of a branch only is
+    //  what the register allocator spills first)
+    request(j00 + AH_SUB * AM_KT);
 
     for (int sub = 0; sub < AH_SUB; ++sub) {
     const int j0 = j00 + sub * AM_KT;
