@@ -19,8 +19,9 @@
 // double-buffered, register-prefetched window when the host asks for 64-row tiles ("small-batch form": grids that would
 // leave the chip idle); gemm_rows_kernel, an LDS-free operand stream for 1-tap convs in the small-batch form; and
 // conv_splitk_f32_kernel, 32 x 32 tiles with the contraction split over the four wavefronts, for fp32 grids of a few workgroups
-// (batch 1).  All share
-// conv_epilogue (bias, per-utterance vector, pre-add, activation, GLU / gated / coupling, residual, accumulate, bf16 I/O).
+// (batch 1).  Every form multiplies TRANSPOSED (the weights are the MFMA A operand), so that a lane's accumulator registers are
+// groups of four consecutive output channels of ONE row, and all share the epilogue arithmetic (epilogue_value: bias, per-utterance
+// vector, pre-add, activation, GLU / gated / coupling, residual, accumulate, 16-bit I/O) behind conv_epilogue_t / conv_epilogue16_t.
 //
 // Reference ops replaced: see include/toucan_tts.h (tts_conv1d).
 #include <cstdio>
