@@ -428,7 +428,8 @@ def main():
     frames_out = int(sum(m.shape[0] for m in out["mel"]))
     audio_s = frames_out * 384 / 24000.0
     # HIP-event time between the completions of consecutive timed steps (event timing, median beside the mean)
-    step_ms = sorted(step_done[i].elapsed_time(step_done[i + 1]) for i in range(args.steps))
+    step_ms_in_order = [step_done[i].elapsed_time(step_done[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_ms_in_order)
     step_ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     # ---- after the timed region: the acoustic model's own rate (one stream, nothing beside it) and the parity check of the
@@ -532,6 +533,7 @@ def main():
             "acoustic_ms_alone": acoustic_alone_ms,
             "vocoder_rtf": t_voc / (args.steps * audio_s),
             "ms_per_step_median_events": step_ms_median, "ms_per_step_min_max_events": [step_ms[0], step_ms[-1]],
+            "ms_per_step_events": [round(v, 2) for v in step_ms_in_order],
             "step_roofline": step_roof,
             "e2e_rtf": elapsed / (args.steps * audio_s * 1.0),
             "abi_calls_per_step": abi_calls,
