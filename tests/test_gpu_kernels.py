@@ -393,7 +393,7 @@ def test_relpos_attention_key_split_form(gpu, cpu, lengths):
         assert torch.equal(g, plain)
 
 
-@pytest.mark.parametrize("lengths", [[640, 37, 128, 1], [129], [700]])
+@pytest.mark.parametrize("lengths", [[640, 37, 128, 1], [129], [700], [97, 33, 65, 32]])  # (two 32-key tiles per step: every way a step can end early)
 def test_relpos_attention_f16(gpu, cpu, lengths):
     """tts_relpos_attention_f16 (the three contractions on the fp16 matrix cores) against the emulator with the same rounding points,
     and against the exact fp32 kernel within the fp16 tolerance."""
